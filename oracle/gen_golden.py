@@ -1,0 +1,272 @@
+"""Pin the oracle against the UNMODIFIED reference and emit tests/golden/*.npz — TEST INFRASTRUCTURE ONLY.
+
+Run in the build container (needs /root/reference):   python -m oracle.gen_golden
+For every item it (1) runs the reference, (2) asserts ``oracle.edmp_oracle`` reproduces it (bit-exact unless a
+tolerance is printed), (3) stores inputs + reference outputs as a fixture.  Fixtures are data only (arrays, parsed
+hyper-parameters); no reference source text is stored.  SURVEY.md §8(c) lists the items G1..G11.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from edmp_amd import guide_cfg as GC  # noqa: E402
+from edmp_amd import scenes as SC  # noqa: E402
+from edmp_amd import weights as W  # noqa: E402
+from oracle import edmp_oracle as O  # noqa: E402
+from oracle import ref_harness  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+T = 255
+TINY_DIMS = (16, 16, 32, 32, 64, 64)
+FULL_DIMS = (32, 64, 128, 256, 512, 512)
+START, GOAL = SC.DEFAULT_START, SC.DEFAULT_GOAL
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    p = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(p, **arrs)
+    print(f"  wrote {name}.npz  {os.path.getsize(p) / 1024:.1f} KiB")
+
+
+def check(name, a, b, tol=0.0):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    both_nan = np.isnan(a) & np.isnan(b)
+    d = np.where(both_nan, 0.0, np.abs(a.astype(np.float64) - b.astype(np.float64)))
+    m = float(d.max()) if d.size else 0.0
+    print(f"  [{name}] oracle vs reference max|diff| = {m:.3e} (tol {tol:g})")
+    assert m <= tol and not np.any(np.isnan(a) ^ np.isnan(b)), name
+
+
+def ref_guide_cfgs(guides, bpg):
+    """Execute the reference driver's own row-array construction (infer_serial.py:56-91) on its own YAML files."""
+    import yaml
+
+    with open(os.path.join(ref_harness.REF, "infer_serial.py")) as f:
+        lines = f.read().split("\n")
+    code = "\n".join(l[4:] if l.startswith("    ") else l for l in lines[55:91])  # de-indent the __main__ body
+
+    def YamlConfig(path):
+        with open(path) as fh:
+            return dict(yaml.safe_load(fh))
+
+    ns = dict(
+        np=np,
+        YamlConfig=YamlConfig,
+        guides=list(guides),
+        T=T,
+        benchmark_cfg={"guide": {"batch_size_per_guide": bpg, "guide_path": ref_harness.REF + "/guides/"}},
+        print=lambda *a, **k: None,
+    )
+    exec(compile(code, "<infer_serial.py:56-91>", "exec"), ns)
+    return ns["guide_cfgs"]
+
+
+def main():
+    torch.manual_seed(0)
+    refd, refg = ref_harness.install(O.PLACEHOLDER_LINK_EXTENTS)
+    import yaml
+
+    # ---------------------------------------------------------------- G1 guide_cfgs
+    print("G1 guide_cfgs")
+    all_guides = sorted(GC.GUIDE_CATALOG)
+    parsed = {}
+    for n in all_guides:
+        with open(f"{ref_harness.REF}/guides/cfgs/guide{n}.yaml") as f:
+            parsed[n] = dict(yaml.safe_load(f))
+        mine = GC.catalog_guide_dict(n)["hyperparameters"]
+        theirs = dict(parsed[n]["hyperparameters"])
+        theirs.pop("batch_size", None)
+        assert mine == theirs, (n, mine, theirs)
+    rc = ref_guide_cfgs(all_guides, 2)
+    oc = O.build_guide_cfgs([parsed[n] for n in all_guides], 2, T)
+    for k in ("clearance", "expansion", "guidance_method", "grad_norm", "guidance_schedule", "volume_trust_region"):
+        check("G1." + k, oc[k], rc[k])
+    save(
+        "g1_guide_cfgs",
+        guides=np.array(all_guides),
+        bpg=np.array(2),
+        hyper_json=np.array(json.dumps({str(n): parsed[n]["hyperparameters"] for n in all_guides})),
+        **{k: rc[k] for k in ("clearance", "expansion", "guidance_method", "grad_norm", "guidance_schedule", "volume_trust_region")},
+    )
+
+    # ---------------------------------------------------------------- G2 schedule
+    print("G2 schedule")
+    dif = refd.Diffusion(T=T, device="cpu")
+    b, a, ab = O.schedule(T)
+    check("G2.beta", b, dif.beta)
+    check("G2.alpha", a, dif.alpha)
+    check("G2.alpha_bar", ab, dif.alpha_bar)
+    save("g2_schedule", beta=dif.beta, alpha=dif.alpha, alpha_bar=dif.alpha_bar)
+
+    # ---------------------------------------------------------------- scene + guides used by G3..G6, G10, G11
+    six = [1, 2, 3, 4, 5, 10]
+    mixed = [1, 10, 11, 18, 9, 13]  # iv/sv x grad_norm on/off, overlapping expansion segments (guide18)
+    scene = SC.random_scene(7, 8)
+    cfg_mixed = ref_guide_cfgs(mixed, 2)
+    Bm = cfg_mixed["total_batch_size"]
+    rg = refg.IntersectionVolumeGuide(scene, "cpu", cfg_mixed, Bm)
+    og = O.GuideOracle(scene, cfg_mixed, Bm)
+    check("link_dimensions", og.link_dims.numpy(), rg.link_dimensions.numpy())
+
+    print("G3 obstacle AABBs")
+    ts = [0, 1, 6, 20, 80, 150, 254, 255]
+    omins, omaxs = [], []
+    for t in ts:
+        rg.define_obstacles(rg.obstacle_config, t)
+        mn, mx = og.obstacles(t)
+        check(f"G3.min t={t}", mn.numpy(), rg.obs_min.numpy())
+        check(f"G3.max t={t}", mx.numpy(), rg.obs_max.numpy())
+        omins.append(rg.obs_min.numpy().copy())
+        omaxs.append(rg.obs_max.numpy().copy())
+    # scipy pin for the quaternion -> matrix restatement
+    from scipy.spatial.transform import Rotation as R
+
+    for i in range(scene.shape[0]):
+        check("quat->R", O.quat_xyzw_to_matrix(scene[i, 3:7]), R.from_quat(scene[i, 3:7]).as_matrix(), 1e-15)
+    save("g3_obstacles", scene=scene, guides=np.array(mixed), bpg=np.array(2), ts=np.array(ts), obs_min=np.stack(omins), obs_max=np.stack(omaxs))
+
+    print("G4 forward kinematics / link transforms")
+    rs = np.random.RandomState(11)
+    lo, hi = O.joint_limits()
+    q = torch.tensor(rs.uniform(lo, hi, (4, 5, 7)), dtype=torch.float32)
+    fk_r = rg.forward_kinematics(q)
+    lt_r = rg.get_link_transform(q)
+    check("G4.fk", O.forward_kinematics(q).numpy(), fk_r.numpy())
+    check("G4.link_T", O.get_link_transform(q).numpy(), lt_r.numpy())
+    save("g4_fk", joints=q.numpy(), fk=fk_r.numpy(), link_T=lt_r.numpy(), link_vertices=rg.link_vertices.numpy())
+
+    print("G5 cost / swept volume")
+    qj = rs.uniform(lo[None, :, None], hi[None, :, None], (Bm, 7, 48))
+    qj += 0.05 * rs.standard_normal(qj.shape)
+    qj = O.clip_joints(qj)
+    vols_iv, vols_sv = {}, {}
+    for t in (0, 6, 128, 254):
+        v_r = rg.cost(torch.tensor(qj, dtype=torch.float32), t)
+        s_r = rg.swept_volume_cost(torch.tensor(qj, dtype=torch.float32), torch.tensor(START, dtype=torch.float32), torch.tensor(GOAL, dtype=torch.float32), t)
+        check(f"G5.iv t={t}", og.cost(qj, t).numpy(), v_r.numpy())
+        check(f"G5.sv t={t}", og.swept_volume_cost(qj, START, GOAL, t).numpy(), s_r.numpy())
+        vols_iv[f"iv_t{t}"] = v_r.numpy()
+        vols_sv[f"sv_t{t}"] = s_r.numpy()
+    save("g5_costs", scene=scene, guides=np.array(mixed), bpg=np.array(2), joints=qj, start=START, goal=GOAL, **vols_iv, **vols_sv)
+
+    print("G6 get_gradient")
+    grads = {}
+    for t in (6, 128, 254):
+        g_r = rg.get_gradient(qj, START, GOAL, t)
+        check(f"G6.grad t={t}", og.get_gradient(qj, START, GOAL, t), g_r, 0.0)
+        grads[f"grad_t{t}"] = g_r
+        print(f"     |g|max={np.nanmax(np.abs(g_r)):.3f} nonzero rows={int((np.abs(g_r).sum((1, 2)) > 0).sum())}/{Bm}")
+    # ties: waypoints pinned at the joint limits (consecutive identical waypoints -> min/max ties in the swept AABB)
+    qt = np.array(qj, copy=True)
+    qt[:, :, 10:20] = hi[None, :, None]
+    qt[:, :, 30:34] = qt[:, :, 30:31]
+    g_r = rg.get_gradient(qt, START, GOAL, 128)
+    check("G6.grad ties", og.get_gradient(qt, START, GOAL, 128), g_r)
+    grads["joints_ties"] = qt
+    grads["grad_ties_t128"] = g_r
+    # Q7: scene far away -> whole-batch gradient is zero -> NaN everywhere
+    far = scene.copy()
+    far[:, 0] += 10.0
+    rgf = refg.IntersectionVolumeGuide(far, "cpu", cfg_mixed, Bm)
+    with np.errstate(all="ignore"):
+        g_far = rgf.get_gradient(qj, START, GOAL, 128)
+        check("G6.grad far (NaN)", O.GuideOracle(far, cfg_mixed, Bm).get_gradient(qj, START, GOAL, 128), g_far)
+    assert np.isnan(g_far).all()
+    # Q7 also holds with NO grad_norm rows: 0 * (0/0) = NaN poisons every row
+    cfg_six = ref_guide_cfgs(six, 2)
+    rg6f = refg.IntersectionVolumeGuide(far, "cpu", cfg_six, 12)
+    with np.errstate(all="ignore"):
+        g_far6 = rg6f.get_gradient(qj, START, GOAL, 128)
+    assert np.isnan(g_far6).all()
+    save("g6_gradient", scene=scene, guides=np.array(mixed), bpg=np.array(2), joints=qj, start=START, goal=GOAL, scene_far=far, **grads)
+
+    print("G7 posterior step")
+    g7 = {}
+    x = rs.standard_normal((3, 7, 50)) * 2.0
+    eps = rs.standard_normal((3, 7, 50)).astype(np.float32)
+    for t in (255, 128, 2, 1):
+        np.random.seed(100 + t)
+        x_r = dif.p_sample_using_posterior(x, t, eps)
+        np.random.seed(100 + t)
+        z = np.random.standard_normal((3, 7, 50))
+        check(f"G7 t={t}", O.p_sample_using_posterior(x, t, eps, z, b, a, ab), x_r)
+        g7[f"x_out_t{t}"] = x_r
+    save("g7_psample", x=x, eps=eps, seed_base=np.array(100), **g7)
+    check("clip", O.clip_joints(x[:, :, 1:-1] * 3), dif.clip_joints(x[:, :, 1:-1] * 3))
+
+    # ---------------------------------------------------------------- G8 UNet
+    print("G8 TemporalUNet")
+    tmp = tempfile.mkdtemp(prefix="edmp_models_")
+    nets = {}
+    for tag, dims, seed in (("tiny", TINY_DIMS, 5), ("full", FULL_DIMS, 6)):
+        net = refd.TemporalUNet(model_name=os.path.join(tmp, tag), input_dim=7, time_dim=32, device="cpu", dims=dims)
+        sd = W.init_state_dict(seed, 7, 32, dims)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        net.train(False)
+        nets[tag] = (net, sd)
+        xb = torch.tensor(rs.standard_normal((3 if tag == "tiny" else 2, 7, 50)), dtype=torch.float32)
+        outs = {}
+        for tt in (255.0, 37.0, 1.0):
+            with torch.no_grad():
+                y_r = net(xb, torch.tensor([tt]))
+            check(f"G8.{tag} t={tt}", O.UNetOracle(sd)(xb, torch.tensor([tt])).numpy(), y_r.numpy())
+            outs[f"eps_t{int(tt)}"] = y_r.numpy()
+        tr = {}
+        with torch.no_grad():
+            O.unet_forward({k: torch.from_numpy(v) for k, v in sd.items()}, xb, torch.tensor([37.0]), trace=tr)
+        save(f"g8_unet_{tag}", seed=np.array(seed), dims=np.array(dims), x=xb.numpy(), **outs, **{"trace_" + k: v.numpy() for k, v in tr.items()})
+
+    # ---------------------------------------------------------------- G9 teacher-forced traces of denoise_guided
+    print("G9 denoise_guided traces (tiny UNet)")
+    net_tiny, sd_tiny = nets["tiny"]
+    keep = [255, 254, 253, 200, 129, 128, 100, 51, 50, 8, 7, 6, 5, 4, 3, 2, 1]
+    for tag, guides, bpg, seed in (("c1_g1_b4", [1], 4, 21), ("c3_g6_b12", six, 2, 22), ("mixed_b12", mixed, 2, 23)):
+        cfgs = ref_guide_cfgs(guides, bpg)
+        B = cfgs["total_batch_size"]
+        rgd = refg.IntersectionVolumeGuide(scene, "cpu", cfgs, B)
+        np.random.seed(seed)
+        X_r = dif.denoise_guided(net_tiny, rgd, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=START, goal=GOAL, condition=True, benchmarking=True)
+        np.random.seed(seed)
+        trace = {}
+        X_o = O.denoise_guided(O.UNetOracle(sd_tiny), O.GuideOracle(scene, cfgs, B), T, 50, 7, cfgs["guidance_schedule"], B, START, GOAL, trace=trace)
+        check(f"G9.{tag} final X", X_o, X_r)
+        vols_r = torch.sum(rgd.swept_volume_cost(torch.tensor(X_r[:, :, 1:-1], dtype=torch.float32), torch.tensor(START, dtype=torch.float32), torch.tensor(GOAL, dtype=torch.float32), 0), dim=(1, 2)).numpy()
+        best_r = rgd.choose_best_trajectory(START, GOAL, X_r)
+        og9 = O.GuideOracle(scene, cfgs, B)
+        check(f"G10.{tag} row volumes", og9.row_swept_volumes(START, GOAL, X_r).numpy(), vols_r)
+        check(f"G10.{tag} best", og9.choose_best_trajectory(START, GOAL, X_r), best_r)
+        arrs = dict(scene=scene, guides=np.array(guides), bpg=np.array(bpg), seed=np.array(seed), start=START, goal=GOAL, X_final=X_r, row_volumes=vols_r, best=best_r, best_index=np.array(int(np.argmin(vols_r))), steps=np.array(keep))
+        for t in keep:
+            s = trace[t]
+            arrs[f"x_in_{t}"] = s["x_in"]
+            arrs[f"eps_{t}"] = s["eps"]
+            arrs[f"x_post_{t}"] = s["x_post"]
+            arrs[f"x_out_{t}"] = s["x_out"]
+            if s["grad"] is not None:
+                arrs[f"grad_{t}"] = s["grad"]
+        save(f"g9_trace_{tag}", **arrs)
+
+    # ---------------------------------------------------------------- G11 IK filter volumes
+    print("G11 IK-filter cost (t=0, batch_size=n, one waypoint)")
+    ik = rs.uniform(lo, hi, (20, 7))
+    v_r = rg.cost(torch.tensor(ik.reshape((-1, 7, 1))), 0, batch_size=ik.shape[0]).sum(axis=(1, 2)).cpu().numpy()
+    v_o = og.cost(ik.reshape((-1, 7, 1)), 0, batch_size=ik.shape[0]).sum(axis=(1, 2)).numpy()
+    check("G11", v_o, v_r)
+    save("g11_ik_filter", scene=scene, ik=ik, volumes=v_r)
+    print("all oracle checks passed; fixtures in", OUT)
+
+
+if __name__ == "__main__":
+    main()
