@@ -1,0 +1,106 @@
+"""ctypes binding of libedmp_hip.so (include/edmp_hip.h).  Fails loudly when the library is missing or does not
+load — there is no CPU fallback for the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libedmp_hip.so")
+
+MAX_LEVELS = 8
+
+
+class UNetDesc(C.Structure):
+    _fields_ = [
+        ("input_dim", C.c_int32),
+        ("time_dim", C.c_int32),
+        ("n_levels", C.c_int32),
+        ("dims", C.c_int32 * MAX_LEVELS),
+        ("horizon", C.c_int32),
+        ("T", C.c_int32),
+    ]
+
+
+class EdmpError(RuntimeError):
+    pass
+
+
+_vp, _i, _d = C.c_void_p, C.c_int, C.c_double
+_pd, _pf, _pi32 = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes); every symbol include/edmp_hip.h declares
+SIGNATURES = {
+    "edmp_last_error": (C.c_char_p, []),
+    "edmp_version": (_i, []),
+    "edmp_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "edmp_ctx_destroy": (None, [_vp]),
+    "edmp_ctx_set_stream": (_i, [_vp, _vp]),
+    "edmp_ctx_synchronize": (_i, [_vp]),
+    "edmp_unet_param_count": (C.c_int64, [C.POINTER(UNetDesc)]),
+    "edmp_unet_load": (_i, [_vp, C.POINTER(UNetDesc), _pf, C.c_int64, _i]),
+    "edmp_unet_forward_dev": (_i, [_vp, _vp, _i, _i, _vp]),
+    "edmp_unet_read_activation_dev": (_i, [_vp, _i, _i, _vp, C.POINTER(_i), C.POINTER(_i)]),
+    "edmp_unet_flops": (_i, [_vp, _pd, _pd]),
+    "edmp_scene_set": (_i, [_vp, _pd, _i, _pd, _pd, _i, _i, _pf, _pf, _pf]),
+    "edmp_rows_set": (_i, [_vp, _pi32, _pf, _pd, _pd, _i, _i]),
+    "edmp_scene_read_aabbs": (_i, [_vp, _i, _i, _pf]),
+    "edmp_guide_cost_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "edmp_guide_swept_cost_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _pf, _pf, _vp]),
+    "edmp_guide_gradient_dev": (_i, [_vp, _vp, _i, _i, _pd, _pd, _i, _vp, _vp]),
+    "edmp_row_swept_volumes_dev": (_i, [_vp, _vp, _i, _i, _pd, _pd, _vp, C.POINTER(_i)]),
+    "edmp_sampler_init": (_i, [_vp, _i, _d]),
+    "edmp_sampler_read_schedule": (_i, [_vp, _pd, _pd, _pd]),
+    "edmp_psample_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "edmp_step_a_dev": (_i, [_vp, _vp, _vp, _i, _i, _pd, _pd, _i, _vp, _vp]),
+    "edmp_step_b_dev": (_i, [_vp, _vp, _i, _i, _pd, _pd, _vp]),
+    "edmp_sumsq_ptr_dev": (_vp, [_vp]),
+    "edmp_denoise_guided_dev": (_i, [_vp, _vp, _i, _pd, _pd, _i, _i, _i, _vp]),
+    "edmp_prof_enable": (_i, [_vp, _i]),
+    "edmp_prof_read": (_i, [_vp, _pd, C.POINTER(C.c_int64), _i]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libedmp_hip.so (built by __graft_entry__.build()).  Raises EdmpError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EdmpError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  edmp_amd has no CPU fallback."
+        )
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise EdmpError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise EdmpError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().edmp_last_error()
+        raise EdmpError(f"{what or 'libedmp_hip'} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def as_pd(a):
+    return a.ctypes.data_as(_pd)
+
+
+def as_pf(a):
+    return a.ctypes.data_as(_pf)
+
+
+def as_pi32(a):
+    return a.ctypes.data_as(_pi32)

@@ -1,0 +1,90 @@
+// common.h — context, error handling and small device helpers shared by the libedmp_hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/edmp_hip.h"
+
+namespace edmp {
+
+void set_error(const char* fmt, ...);
+
+#define EDMP_HIP_CHECK(expr)                                                                      \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            edmp::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return EDMP_ERR_HIP;                                                                  \
+        }                                                                                         \
+    } while (0)
+
+#define EDMP_REQUIRE(cond, ...)           \
+    do {                                  \
+        if (!(cond)) {                    \
+            edmp::set_error(__VA_ARGS__); \
+            return EDMP_ERR_ARG;          \
+        }                                 \
+    } while (0)
+
+struct UNet;     // unet.hip
+struct Guide;    // guide.hip
+struct Sampler;  // sampler.hip
+
+struct Prof {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // recorded, not yet read
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    double conv_ms = 0.0;
+    int64_t conv_launches = 0;
+};
+
+}  // namespace edmp
+
+struct edmp_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    edmp::UNet* unet = nullptr;
+    edmp::Guide* guide = nullptr;
+    edmp::Sampler* sampler = nullptr;
+    edmp::Prof prof;
+};
+
+namespace edmp {
+
+void unet_destroy(UNet*);
+void guide_destroy(Guide*);
+void sampler_destroy(Sampler*);
+
+// RAII-less helper: device allocation tracked by the owner
+template <class T>
+inline hipError_t dev_alloc(T** p, size_t n) {
+    return hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T));
+}
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// x * tanh(softplus(x)) with torch's softplus threshold (20): blocks.py:27,65 -> torch.nn.Mish
+__device__ __forceinline__ float mish_f(float x) {
+    float sp = (x > 20.0f) ? x : log1pf(expf(x));
+    return x * tanhf(sp);
+}
+
+}  // namespace edmp

@@ -1,0 +1,365 @@
+// sampler.hip — the guided reverse-diffusion loop (Diffusion.denoise_guided) and the C-ABI context plumbing.
+//
+// Replaces (reference diffusion/diffusion.py): __init__/schedule_variance :10-20,37-49, p_sample_using_posterior
+// :116-135, clip_joints :280-298 (inside the guide kernel), denoise_guided :300-356, denoise :253-278.
+// State X is float64 on device exactly like the reference's NumPy state; the UNet sees float32(X), eps (f32) is
+// promoted to f64 in the posterior; the noise stream z is an input (host NumPy RNG order is part of the contract).
+#include "common.h"
+
+namespace edmp {
+
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+// unet.hip / guide.hip
+int unet_forward_impl(edmp_ctx* ctx, const float* x_dev, int B, int t, float* eps_dev);
+int guide_raw_gradient_from_X(edmp_ctx* ctx, const double* X_dev, int B, int N, int t);
+int guide_set_startgoal(edmp_ctx* ctx, const double* start, const double* goal);
+const float* guide_graw(edmp_ctx* ctx);
+const double* guide_grad_norm(edmp_ctx* ctx);
+const double* guide_sched(edmp_ctx* ctx);
+double* guide_sumsq(edmp_ctx* ctx);
+int guide_rows_T(edmp_ctx* ctx);
+
+struct Sampler {
+    int T = 0;
+    std::vector<double> beta, alpha, alpha_bar, c1, sqrt_alpha;  // host tables (f64)
+    // scratch for the loop
+    float* x32 = nullptr;   // (B,C,N) f32 UNet input
+    float* eps = nullptr;   // (B,C,N) f32
+    double* X = nullptr;    // (B,C,N) f64 loop state
+    double* sg = nullptr;   // [14] start|goal f64
+    int cap = 0;            // elements
+};
+
+void sampler_destroy(Sampler* s) {
+    if (!s) return;
+    for (void* p : {(void*)s->x32, (void*)s->eps, (void*)s->X, (void*)s->sg})
+        if (p) (void)hipFree(p);
+    delete s;
+}
+
+__global__ void f64_to_f32_kernel(const double* __restrict__ x, float* __restrict__ y, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (float)x[i];
+}
+
+// x <- (x - c1 * eps) / sqrt(alpha) + beta * z ; quirk Q3: z of (global) row 0 is zeroed at t == 1
+__global__ void psample_kernel(double* __restrict__ X, const float* __restrict__ eps, const double* __restrict__ z, int n, int per_row,
+                               double c1, double sqrt_alpha, double beta, int zero_row0) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double zz = z[i];
+    if (zero_row0 && i < per_row) zz = 0.0;
+    X[i] = (X[i] - c1 * (double)eps[i]) / sqrt_alpha + beta * zz;
+}
+
+// X[:, :, 1:-1] -= sched[:, t-1] * ((1-gn) g + gn g/||g||);  then X[:, :, 0] = start, X[:, :, -1] = goal
+__global__ void update_kernel(double* __restrict__ X, const float* __restrict__ graw, const double* __restrict__ sumsq,
+                              const double* __restrict__ grad_norm, const double* __restrict__ sched, int sched_T, int t, int B, int C, int N,
+                              const double* __restrict__ sg, int guided, double* __restrict__ grad_out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C * N) return;
+    const int l = i % N;
+    const int c = (i / N) % C;
+    const int b = i / (N * C);
+    if (l == 0) {
+        X[i] = sg[c];
+    } else if (l == N - 1) {
+        X[i] = sg[7 + c];
+    } else if (guided) {
+        const int L = N - 2;
+        const size_t gi = ((size_t)b * C + c) * L + (l - 1);
+        const float nrm = (float)sqrt(sumsq[0]);
+        const float gv = graw[gi];
+        const double gn = grad_norm[b];
+        const double mixed = (1.0 - gn) * (double)gv + gn * (double)(gv / nrm);
+        X[i] = X[i] - sched[(size_t)b * sched_T + (t - 1)] * mixed;
+        if (grad_out) grad_out[gi] = mixed;
+    }
+}
+
+__global__ void condition_kernel(double* __restrict__ X, int B, int C, int N, const double* __restrict__ sg) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;  // over B*C
+    if (i >= B * C) return;
+    int c = i % C;
+    X[(size_t)i * N] = sg[c];
+    X[(size_t)i * N + N - 1] = sg[7 + c];
+}
+
+static int ensure_sampler_scratch(edmp_ctx* ctx, int n) {
+    Sampler* s = ctx->sampler;
+    if (s->cap >= n) return EDMP_OK;
+    for (void* p : {(void*)s->x32, (void*)s->eps, (void*)s->X})
+        if (p) (void)hipFree(p);
+    s->x32 = nullptr;
+    s->eps = nullptr;
+    s->X = nullptr;
+    EDMP_HIP_CHECK(hipMalloc((void**)&s->x32, (size_t)n * sizeof(float)));
+    EDMP_HIP_CHECK(hipMalloc((void**)&s->eps, (size_t)n * sizeof(float)));
+    EDMP_HIP_CHECK(hipMalloc((void**)&s->X, (size_t)n * sizeof(double)));
+    s->cap = n;
+    return EDMP_OK;
+}
+
+static bool guided_step(int t) { return (t % 2) < 1 && t >= 5; }  // diffusion.py:311,326-327 (period 2)
+
+static int set_startgoal(edmp_ctx* ctx, const double* start, const double* goal, bool need_guide) {
+    Sampler* s = ctx->sampler;
+    double sg[14];
+    for (int i = 0; i < 7; ++i) {
+        sg[i] = start[i];
+        sg[7 + i] = goal[i];
+    }
+    EDMP_HIP_CHECK(hipMemcpyAsync(s->sg, sg, sizeof(sg), hipMemcpyHostToDevice, ctx->stream));
+    EDMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (need_guide) return guide_set_startgoal(ctx, start, goal);
+    return EDMP_OK;
+}
+
+static int step_a(edmp_ctx* ctx, double* X, const double* z, int B, int t, int zero_row0, int guided, float* eps_out, double* xpost_out) {
+    Sampler* s = ctx->sampler;
+    const int C = ctx->unet->desc.input_dim, N = ctx->unet->desc.horizon;
+    const int n = B * C * N;
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, st, X, s->x32, n);
+    int rc = unet_forward_impl(ctx, s->x32, B, t, s->eps);
+    if (rc) return rc;
+    if (eps_out) EDMP_HIP_CHECK(hipMemcpyAsync(eps_out, s->eps, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(psample_kernel, dim3((n + 255) / 256), dim3(256), 0, st, X, s->eps, z, n, C * N, s->c1[t - 1], s->sqrt_alpha[t - 1],
+                       s->beta[t - 1], (zero_row0 && t == 1) ? 1 : 0);
+    EDMP_HIP_CHECK(hipGetLastError());
+    if (xpost_out) EDMP_HIP_CHECK(hipMemcpyAsync(xpost_out, X, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (guided && guided_step(t)) {
+        rc = guide_raw_gradient_from_X(ctx, X, B, N, t);
+        if (rc) return rc;
+    }
+    return EDMP_OK;
+}
+
+static int step_b(edmp_ctx* ctx, double* X, int B, int t, int guided, double* grad_out) {
+    Sampler* s = ctx->sampler;
+    const int C = ctx->unet->desc.input_dim, N = ctx->unet->desc.horizon;
+    hipStream_t st = ctx->stream;
+    if (guided && guided_step(t)) {
+        const int n = B * C * N;
+        hipLaunchKernelGGL(update_kernel, dim3((n + 255) / 256), dim3(256), 0, st, X, guide_graw(ctx), guide_sumsq(ctx), guide_grad_norm(ctx),
+                           guide_sched(ctx), guide_rows_T(ctx), t, B, C, N, s->sg, 1, grad_out);
+    } else {
+        hipLaunchKernelGGL(condition_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, X, B, C, N, s->sg);
+    }
+    EDMP_HIP_CHECK(hipGetLastError());
+    return EDMP_OK;
+}
+
+}  // namespace edmp
+
+using namespace edmp;
+
+extern "C" const char* edmp_last_error(void) { return g_err.c_str(); }
+extern "C" int edmp_version(void) { return 100; }
+
+extern "C" int edmp_ctx_create(int device, edmp_ctx** out) {
+    EDMP_REQUIRE(out, "edmp_ctx_create: null out pointer");
+    int ndev = 0;
+    EDMP_HIP_CHECK(hipGetDeviceCount(&ndev));
+    EDMP_REQUIRE(device >= 0 && device < ndev, "device %d not present (%d visible)", device, ndev);
+    EDMP_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    EDMP_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; libedmp_hip is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return EDMP_ERR_STATE;
+    }
+    edmp_ctx* c = new edmp_ctx();
+    c->device = device;
+    EDMP_HIP_CHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    *out = c;
+    return EDMP_OK;
+}
+
+extern "C" void edmp_ctx_destroy(edmp_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    unet_destroy(ctx->unet);
+    guide_destroy(ctx->guide);
+    sampler_destroy(ctx->sampler);
+    for (auto& e : ctx->prof.pending) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    for (auto& e : ctx->prof.pool) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" int edmp_ctx_set_stream(edmp_ctx* ctx, void* hip_stream) {
+    EDMP_REQUIRE(ctx, "null ctx");
+    EDMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return EDMP_OK;
+}
+
+extern "C" int edmp_ctx_synchronize(edmp_ctx* ctx) {
+    EDMP_REQUIRE(ctx, "null ctx");
+    EDMP_HIP_CHECK(hipSetDevice(ctx->device));
+    EDMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return EDMP_OK;
+}
+
+extern "C" int edmp_sampler_init(edmp_ctx* ctx, int T, double variance_thresh) {
+    EDMP_REQUIRE(ctx && T >= 1, "edmp_sampler_init: bad arguments");
+    EDMP_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->sampler) {
+        ctx->sampler = new Sampler();
+        EDMP_HIP_CHECK(hipMalloc((void**)&ctx->sampler->sg, 14 * sizeof(double)));
+    }
+    Sampler* s = ctx->sampler;
+    s->T = T;
+    s->beta.resize(T);
+    s->alpha.resize(T);
+    s->alpha_bar.resize(T);
+    s->c1.resize(T);
+    s->sqrt_alpha.resize(T);
+    // np.linspace(0, thresh, T+1)[1:]: start + i*step with step = (stop-start)/T, last element forced to stop
+    const double step = variance_thresh / (double)T;
+    double prod = 1.0;
+    for (int i = 1; i <= T; ++i) {
+        double b = (i == T) ? variance_thresh : (double)i * step;
+        s->beta[i - 1] = b;
+        s->alpha[i - 1] = 1.0 - b;
+        prod *= s->alpha[i - 1];  // np.prod(alpha[:t]) multiplies left to right
+        s->alpha_bar[i - 1] = prod;
+        s->c1[i - 1] = (1.0 - s->alpha[i - 1]) / sqrt(1.0 - s->alpha_bar[i - 1]);
+        s->sqrt_alpha[i - 1] = sqrt(s->alpha[i - 1]);
+    }
+    return EDMP_OK;
+}
+
+extern "C" int edmp_sampler_read_schedule(edmp_ctx* ctx, double* beta, double* alpha, double* alpha_bar) {
+    EDMP_REQUIRE(ctx && ctx->sampler, "sampler not initialised");
+    Sampler* s = ctx->sampler;
+    if (beta) memcpy(beta, s->beta.data(), s->T * sizeof(double));
+    if (alpha) memcpy(alpha, s->alpha.data(), s->T * sizeof(double));
+    if (alpha_bar) memcpy(alpha_bar, s->alpha_bar.data(), s->T * sizeof(double));
+    return EDMP_OK;
+}
+
+extern "C" int edmp_psample_dev(edmp_ctx* ctx, double* X_dev, const float* eps_dev, const double* z_dev, int B, int C, int N, int t,
+                                int zero_row0) {
+    EDMP_REQUIRE(ctx && ctx->sampler && X_dev && eps_dev && z_dev, "edmp_psample_dev: bad arguments / sampler not initialised");
+    Sampler* s = ctx->sampler;
+    EDMP_REQUIRE(t >= 1 && t <= s->T, "t=%d outside 1..%d", t, s->T);
+    EDMP_HIP_CHECK(hipSetDevice(ctx->device));
+    const int n = B * C * N;
+    hipLaunchKernelGGL(psample_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, X_dev, eps_dev, z_dev, n, C * N, s->c1[t - 1],
+                       s->sqrt_alpha[t - 1], s->beta[t - 1], (zero_row0 && t == 1) ? 1 : 0);
+    EDMP_HIP_CHECK(hipGetLastError());
+    return EDMP_OK;
+}
+
+static int check_loop_state(edmp_ctx* ctx, int B, bool guided) {
+    EDMP_REQUIRE(ctx && ctx->sampler && ctx->unet, "sampler / model not initialised");
+    EDMP_REQUIRE(ctx->unet->desc.input_dim == 7 || !guided, "the guide needs 7 joint channels");
+    EDMP_REQUIRE(ctx->sampler->T <= ctx->unet->desc.T, "sampler T exceeds the model's time-bias table");
+    EDMP_REQUIRE(B >= 1 && B <= ctx->unet->max_batch, "batch %d outside 1..%d", B, ctx->unet->max_batch);
+    if (guided) EDMP_REQUIRE(ctx->guide && ctx->guide->aabb && ctx->guide->row_class, "scene / rows not set");
+    return EDMP_OK;
+}
+
+extern "C" int edmp_step_a_dev(edmp_ctx* ctx, double* X_dev, const double* z_dev, int B, int t, const double* start, const double* goal,
+                               int zero_row0, float* eps_out_dev, double* xpost_out_dev) {
+    int rc = check_loop_state(ctx, B, true);
+    if (rc) return rc;
+    EDMP_REQUIRE(X_dev && z_dev && start && goal, "null pointer");
+    EDMP_REQUIRE(t >= 1 && t <= ctx->sampler->T, "t out of range");
+    EDMP_HIP_CHECK(hipSetDevice(ctx->device));
+    const int n = B * ctx->unet->desc.input_dim * ctx->unet->desc.horizon;
+    rc = ensure_sampler_scratch(ctx, n);
+    if (rc) return rc;
+    rc = set_startgoal(ctx, start, goal, true);
+    if (rc) return rc;
+    return step_a(ctx, X_dev, z_dev, B, t, zero_row0, 1, eps_out_dev, xpost_out_dev);
+}
+
+extern "C" int edmp_step_b_dev(edmp_ctx* ctx, double* X_dev, int B, int t, const double* start, const double* goal, double* grad_out_dev) {
+    int rc = check_loop_state(ctx, B, true);
+    if (rc) return rc;
+    EDMP_REQUIRE(X_dev && start && goal, "null pointer");
+    EDMP_HIP_CHECK(hipSetDevice(ctx->device));
+    rc = set_startgoal(ctx, start, goal, false);
+    if (rc) return rc;
+    return step_b(ctx, X_dev, B, t, 1, grad_out_dev);
+}
+
+extern "C" double* edmp_sumsq_ptr_dev(edmp_ctx* ctx) { return ctx ? guide_sumsq(ctx) : nullptr; }
+
+extern "C" int edmp_denoise_guided_dev(edmp_ctx* ctx, const double* noise_dev, int B, const double* start, const double* goal, int guided,
+                                       int t_stop, int zero_row0, double* X_out_dev) {
+    int rc = check_loop_state(ctx, B, guided != 0);
+    if (rc) return rc;
+    EDMP_REQUIRE(noise_dev && start && goal && X_out_dev, "null pointer");
+    Sampler* s = ctx->sampler;
+    const int T = s->T;
+    EDMP_REQUIRE(t_stop >= 0 && t_stop < T, "t_stop out of range");
+    EDMP_HIP_CHECK(hipSetDevice(ctx->device));
+    const int C = ctx->unet->desc.input_dim, N = ctx->unet->desc.horizon;
+    const size_t n = (size_t)B * C * N;
+    rc = ensure_sampler_scratch(ctx, (int)n);
+    if (rc) return rc;
+    rc = set_startgoal(ctx, start, goal, guided != 0);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    // X_T = noise[0] with start/goal conditioning                                       diffusion.py:303-307
+    EDMP_HIP_CHECK(hipMemcpyAsync(s->X, noise_dev, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(condition_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, s->X, B, C, N, s->sg);
+    for (int t = T; t > t_stop; --t) {
+        const double* z = noise_dev + (size_t)(1 + (T - t)) * n;
+        rc = step_a(ctx, s->X, z, B, t, zero_row0, guided, nullptr, nullptr);
+        if (rc) return rc;
+        rc = step_b(ctx, s->X, B, t, guided, nullptr);
+        if (rc) return rc;
+    }
+    EDMP_HIP_CHECK(hipMemcpyAsync(X_out_dev, s->X, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return EDMP_OK;
+}
+
+extern "C" int edmp_prof_enable(edmp_ctx* ctx, int on) {
+    EDMP_REQUIRE(ctx, "null ctx");
+    ctx->prof.on = on != 0;
+    return EDMP_OK;
+}
+
+extern "C" int edmp_prof_read(edmp_ctx* ctx, double* conv_ms, int64_t* conv_launches, int reset) {
+    EDMP_REQUIRE(ctx, "null ctx");
+    EDMP_HIP_CHECK(hipSetDevice(ctx->device));
+    EDMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    Prof& p = ctx->prof;
+    for (auto& e : p.pending) {
+        float ms = 0.f;
+        EDMP_HIP_CHECK(hipEventElapsedTime(&ms, e.first, e.second));
+        p.conv_ms += ms;
+        p.conv_launches += 1;
+        p.pool.push_back(e);
+    }
+    p.pending.clear();
+    if (conv_ms) *conv_ms = p.conv_ms;
+    if (conv_launches) *conv_launches = p.conv_launches;
+    if (reset) {
+        p.conv_ms = 0.0;
+        p.conv_launches = 0;
+    }
+    return EDMP_OK;
+}

@@ -1,0 +1,901 @@
+// unet.hip — TemporalUNet eps-prediction for gfx950 (MI355X), fp32 end to end.
+//
+// Replaces TemporalUNet.forward and the blocks it is built from (reference: diffusion/models/temporalunet.py:47-76,
+// diffusion/models/blocks.py:13-34 Conv1dBlock, :38-92 time embedding, :137-166 ResidualConvolutionBlock,
+// :202-260 Down/Middle/Up samplers).  Design:
+//   * activations live in HBM as [B][L][C] fp32 (channels innermost) so that every conv tap of one output position
+//     is a contiguous C-vector per sample; conv weights are repacked once to [tap][Cout][Cin].
+//   * every Conv1d / ConvTranspose1d is an implicit GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32):
+//     M = samples, N = (output position, Cout tile), K = (valid taps) x Cin.  Because a workgroup's N-tile has ONE
+//     output position, taps that fall into the zero padding are skipped entirely (at L=2 only 2 of 5 taps exist).
+//   * GroupNorm(8) + Mish + (time-bias | residual) is one wave per (sample, group), register resident, two-pass
+//     statistics; the whole time-embedding MLP chain depends on t only and is precomputed for t = 1..T at load.
+#include "common.h"
+
+namespace edmp {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// ---------------------------------------------------------------------------------------------------------------
+// parameter inventory (state-dict order; mirrors edmp_amd/weights.py:unet_param_shapes)
+// ---------------------------------------------------------------------------------------------------------------
+struct RawT {
+    int64_t off;  // float offset in the flat blob
+    int d0, d1, d2;
+};
+struct RawConvBlock {
+    RawT w, b, gw, gb;
+};
+struct RawRCB {
+    RawConvBlock cb[2];
+    RawT tw, tb;
+    bool has_res;
+    RawT rw, rb;
+    int cin, cout;
+};
+struct RawNet {
+    RawT t1w, t1b, t3w, t3b;
+    std::vector<RawRCB> rcbs;  // down (2 per level), middle (2), up (2 per level)
+    std::vector<RawT> down_w, down_b, up_w, up_b;
+    RawConvBlock final_cb;
+    RawT final_w, final_b;
+    int64_t total = 0;
+};
+
+static RawT take(int64_t& off, int d0, int d1 = 1, int d2 = 1) {
+    RawT t{off, d0, d1, d2};
+    off += (int64_t)d0 * d1 * d2;
+    return t;
+}
+static RawConvBlock take_cb(int64_t& off, int cin, int cout, int k) {
+    RawConvBlock c;
+    c.w = take(off, cout, cin, k);
+    c.b = take(off, cout);
+    c.gw = take(off, cout);
+    c.gb = take(off, cout);
+    return c;
+}
+static RawRCB take_rcb(int64_t& off, int cin, int cout, int time_dim) {
+    RawRCB r;
+    r.cin = cin;
+    r.cout = cout;
+    r.cb[0] = take_cb(off, cin, cout, 5);
+    r.cb[1] = take_cb(off, cout, cout, 5);
+    r.tw = take(off, cout, time_dim);
+    r.tb = take(off, cout);
+    r.has_res = cin != cout;
+    if (r.has_res) {
+        r.rw = take(off, cout, cin, 1);
+        r.rb = take(off, cout);
+    }
+    return r;
+}
+static RawNet inventory(const edmp_unet_desc& d) {
+    RawNet n;
+    int64_t off = 0;
+    std::vector<int> dm{d.input_dim};
+    for (int i = 0; i < d.n_levels; ++i) dm.push_back(d.dims[i]);
+    const int td = d.time_dim;
+    n.t1w = take(off, td * 4, td);
+    n.t1b = take(off, td * 4);
+    n.t3w = take(off, td, td * 4);
+    n.t3b = take(off, td);
+    const int nd = d.n_levels;
+    for (int i = 0; i < nd; ++i) {
+        n.rcbs.push_back(take_rcb(off, dm[i], dm[i + 1], td));
+        n.rcbs.push_back(take_rcb(off, dm[i + 1], dm[i + 1], td));
+        if (i != nd - 1) {
+            n.down_w.push_back(take(off, dm[i + 1], dm[i + 1], 3));
+            n.down_b.push_back(take(off, dm[i + 1]));
+        }
+    }
+    n.rcbs.push_back(take_rcb(off, dm[nd], dm[nd], td));
+    n.rcbs.push_back(take_rcb(off, dm[nd], dm[nd], td));
+    for (int i = nd; i > 1; --i) {
+        n.rcbs.push_back(take_rcb(off, dm[i] * 2, dm[i - 1], td));
+        n.rcbs.push_back(take_rcb(off, dm[i - 1], dm[i - 1], td));
+        n.up_w.push_back(take(off, dm[i - 1], dm[i - 1], 4));
+        n.up_b.push_back(take(off, dm[i - 1]));
+    }
+    n.final_cb = take_cb(off, dm[1], dm[1], 5);
+    n.final_w = take(off, d.input_dim, dm[1], 1);
+    n.final_b = take(off, d.input_dim);
+    n.total = off;
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// device program
+// ---------------------------------------------------------------------------------------------------------------
+struct ConvP {
+    const float* src1;
+    const float* src2;  // second half of a channel concat, or nullptr
+    int C1, C2;         // channels of src1 / src2 (storage widths)
+    int Lin, Lout;
+    int ntaps, stride, pad, transposed;
+    const float* W;  // [tap][Cout][C1 + C2]
+    const float* bias;
+    float* dst;  // [B][Lout][Cout]
+    int Cout;
+    int B;
+};
+
+struct GnP {
+    float* y;  // [B][L][C], normalised in place
+    const float* gamma;
+    const float* beta;
+    const float* add_res;    // [B][L][C] or nullptr
+    const float* add_tbias;  // [C] (already offset to step t) or nullptr
+    int L, C, B;
+};
+
+enum OpKind { OP_CONV = 0, OP_GN = 1 };
+struct Op {
+    OpKind kind;
+    ConvP cv;
+    GnP gn;
+    int tb_off;   // GN: offset into the time-bias row, -1 if none
+    double flops_nominal, flops_exec;  // CONV: per trajectory
+};
+
+struct UNet {
+    edmp_unet_desc desc{};
+    int max_batch = 0;
+    float* wpack = nullptr;    // repacked conv weights + biases + gn affine
+    float* tbias = nullptr;    // [T][tb_stride]
+    int tb_stride = 0;
+    std::vector<float*> bufs;  // activation buffers
+    size_t buf_cap = 0;        // floats per buffer
+    std::vector<Op> prog;
+    float* x_in = nullptr;   // [B][N][8]
+    float* h_last = nullptr;  // [B][N][C1] input of the 1x1 head
+    const float* head_w = nullptr;
+    const float* head_b = nullptr;
+    int head_cin = 0;
+    // taps of intermediate activations for parity (buffer, C, L); valid right after a forward
+    struct Tap { int which; const float* p; int C, L; };
+    std::vector<Tap> taps;
+    double flops_nominal = 0, flops_exec = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------------
+
+// (B, C, N) f32 -> [B][N][CP] f32 with zero padding of channels C..CP-1.
+__global__ void pack_input_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int C, int N, int CP) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;  // over B*N*CP
+    int total = B * N * CP;
+    if (i >= total) return;
+    int c = i % CP;
+    int l = (i / CP) % N;
+    int b = i / (CP * N);
+    out[i] = (c < C) ? x[((size_t)b * C + c) * N + l] : 0.0f;
+}
+
+// Implicit-GEMM Conv1d / ConvTranspose1d on the fp32 MFMA.  Block = 256 threads = 4 waves, tile BM samples x BN
+// output channels at ONE output position; K runs over (valid tap, source, channel chunk of KC).
+// LDS tiles are [rows][KC + 4] so that the ds_read_b128 of a 16-lane group hits 16 distinct 4-bank slots.
+template <int BM, int BN, int KC>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
+    constexpr int LDK = KC + 4;
+    constexpr int WN = BN / 32;
+    constexpr int F4_PER_ROW = KC / 4;
+    constexpr int A_F4 = BM * F4_PER_ROW;
+    constexpr int B_F4 = BN * F4_PER_ROW;
+    constexpr int A_IT = (A_F4 + 255) / 256;
+    constexpr int B_IT = (B_F4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDK];
+    constexpr int STAGE = (BM + BN) * LDK;  // floats per pipeline stage: A tile then B tile
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntn = (p.Cout + BN - 1) / BN;
+    const int lo = blockIdx.y / ntn;
+    const int n0 = (blockIdx.y % ntn) * BN;
+    const int b0 = blockIdx.x * BM;
+    const int Cin = p.C1 + p.C2;
+
+    // valid taps for this output position (block-uniform), kept in LDS so that no runtime-indexed register array
+    // (= scratch memory) is created
+    __shared__ int s_tap[8], s_li[8], s_nvt;
+    if (tid == 0) {
+        int n = 0;
+        for (int k = 0; k < p.ntaps; ++k) {
+            int li;
+            bool ok;
+            if (!p.transposed) {
+                li = lo * p.stride + k - p.pad;
+                ok = (li >= 0) && (li < p.Lin);
+            } else {
+                int num = lo + p.pad - k;
+                li = num / p.stride;
+                ok = (num >= 0) && (num % p.stride == 0) && (li < p.Lin);
+            }
+            if (ok) {
+                s_tap[n] = k;
+                s_li[n] = li;
+                ++n;
+            }
+        }
+        s_nvt = n;
+    }
+    __syncthreads();
+    const int nvt = s_nvt;
+    const int ch1 = p.C1 / KC, ch2 = p.C2 / KC;
+    const int chunks_per_tap = ch1 + ch2;
+    const int nK = nvt * chunks_per_tap;
+
+    float4 ra[A_IT], rb[B_IT];
+
+    auto load_chunk = [&](int kk) {
+        int ti = kk / chunks_per_tap;
+        int cc = kk - ti * chunks_per_tap;
+        const int tap = s_tap[ti], li = s_li[ti];
+        const float* src;
+        int Cs, ci0, wofs;
+        if (cc < ch1) {
+            src = p.src1;
+            Cs = p.C1;
+            ci0 = cc * KC;
+            wofs = ci0;
+        } else {
+            src = p.src2;
+            Cs = p.C2;
+            ci0 = (cc - ch1) * KC;
+            wofs = p.C1 + ci0;
+        }
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            int f = tid + it * 256;
+            int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < A_F4 && (b0 + r) < p.B)
+                v = *reinterpret_cast<const float4*>(src + ((size_t)(b0 + r) * p.Lin + li) * Cs + ci0 + c4 * 4);
+            ra[it] = v;
+        }
+        const float* wt = p.W + (size_t)tap * p.Cout * Cin + wofs;
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            int f = tid + it * 256;
+            int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < B_F4 && (n0 + r) < p.Cout) v = *reinterpret_cast<const float4*>(wt + (size_t)(n0 + r) * Cin + c4 * 4);
+            rb[it] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            int f = tid + it * 256;
+            int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
+            if (f < A_F4) *reinterpret_cast<float4*>(lds + buf * STAGE + r * LDK + c4 * 4) = ra[it];
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            int f = tid + it * 256;
+            int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
+            if (f < B_F4) *reinterpret_cast<float4*>(lds + buf * STAGE + BM * LDK + r * LDK + c4 * 4) = rb[it];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+
+    if (nK > 0) {
+        load_chunk(0);
+        store_chunk(0);
+    }
+    __syncthreads();
+    const int arow = (wm * 32 + (lane & 31)) * LDK + 4 * (lane >> 5);
+    const int brow = (wn * 32 + (lane & 31)) * LDK + 4 * (lane >> 5);
+    for (int kk = 0; kk < nK; ++kk) {
+        const int cur = kk & 1;
+        if (kk + 1 < nK) load_chunk(kk + 1);
+        const float* a_s = lds + cur * STAGE + arow;
+        const float* b_s = lds + cur * STAGE + BM * LDK + brow;
+#pragma unroll
+        for (int j = 0; j < KC / 8; ++j) {
+            float4 a4 = *reinterpret_cast<const float4*>(a_s + 8 * j);
+            float4 b4 = *reinterpret_cast<const float4*>(b_s + 8 * j);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
+        if (kk + 1 < nK) store_chunk(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: + bias, store [b][lo][co].  acc[r]: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+    const int co = n0 + wn * 32 + (lane & 31);
+    if (co < p.Cout) {
+        const float bias = p.bias[co];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            int b = b0 + wm * 32 + row;
+            if (b < p.B) p.dst[((size_t)b * p.Lout + lo) * p.Cout + co] = acc[r] + bias;
+        }
+    }
+}
+
+// GroupNorm(8 groups, eps 1e-5, biased variance) -> Mish -> (+ time bias[c] | + residual[b,l,c]) in place.
+// One wave per (sample, group); the (C/8) x L elements of the group stay in registers between the passes.
+template <int EPL>  // elements per lane
+__global__ __launch_bounds__(256) void gn_mish_kernel(GnP p) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);  // global wave = b*8 + g
+    if (gw >= p.B * 8) return;
+    const int b = gw >> 3, g = gw & 7;
+    const int cg = p.C >> 3;
+    const int n = cg * p.L;
+    float* base = p.y + (size_t)b * p.L * p.C + g * cg;
+    float v[EPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        int e = lane + i * 64;
+        float x = 0.f;
+        if (e < n) {
+            int l = e / cg, c = e - l * cg;
+            x = base[(size_t)l * p.C + c];
+        }
+        v[i] = x;
+        s += x;
+    }
+    const float mean = wave_sum(s) / (float)n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        int e = lane + i * 64;
+        float d = (e < n) ? (v[i] - mean) : 0.f;
+        q += d * d;
+    }
+    const float var = wave_sum(q) / (float)n;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        int e = lane + i * 64;
+        if (e < n) {
+            int l = e / cg, c = e - l * cg;
+            int ch = g * cg + c;
+            float scale = rstd * p.gamma[ch];
+            float shift = p.beta[ch] - scale * mean;
+            float y = mish_f(v[i] * scale + shift);
+            if (p.add_tbias) y += p.add_tbias[ch];
+            if (p.add_res) y += p.add_res[((size_t)b * p.L + l) * p.C + ch];
+            base[(size_t)l * p.C + c] = y;
+        }
+    }
+}
+
+// final 1x1 conv (final_conv.1, temporalunet.py:36): h [B][N][Cin] -> eps (B, Cout, N) in the reference layout.
+__global__ void head_1x1_kernel(const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ bias,
+                                float* __restrict__ eps, int B, int N, int Cin, int Cout) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;  // over B*N
+    if (i >= B * N) return;
+    int b = i / N, l = i - b * N;
+    const float* hp = h + (size_t)i * Cin;
+    for (int co = 0; co < Cout; ++co) {
+        float a = bias[co];
+        for (int ci = 0; ci < Cin; ++ci) a = fmaf(hp[ci], w[co * Cin + ci], a);
+        eps[((size_t)b * Cout + co) * N + l] = a;
+    }
+}
+
+// [B][L][C] -> (B, C, L)   (parity/debug only)
+__global__ void unpack_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int L, int C) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * L * C) return;
+    int l = i % L;
+    int c = (i / L) % C;
+    int b = i / (L * C);
+    dst[i] = src[((size_t)b * L + l) * C + c];
+}
+
+// time-bias table: for t = 1..T (blockIdx.x = t-1): temb = Linear(Mish(Linear(sinusoid(t))));  row[c] = tb[c] +
+// sum_k tw[c][k] * Mish(temb[k]) for the concatenated per-RCB time MLPs.  blocks.py:46-54, 83-88, 64-67.
+__global__ void time_table_kernel(const float* __restrict__ t1w, const float* __restrict__ t1b, const float* __restrict__ t3w,
+                                  const float* __restrict__ t3b, const float* __restrict__ tw, const float* __restrict__ tb,
+                                  float* __restrict__ out, int time_dim, int stride) {
+    extern __shared__ float sm[];  // emb[time_dim] | hid[4*time_dim] | temb[time_dim]
+    float* emb = sm;
+    float* hid = sm + time_dim;
+    float* temb = hid + 4 * time_dim;
+    const float t = (float)(blockIdx.x + 1);
+    const int half = time_dim / 2;
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        float e = (float)(log(10000.0) / (double)(half - 1));  // python float, then cast when multiplied into f32
+        float f = expf((float)i * -e);
+        float a = t * f;
+        emb[i] = sinf(a);
+        emb[i + half] = cosf(a);
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 4 * time_dim; o += blockDim.x) {
+        float a = t1b[o];
+        for (int k = 0; k < time_dim; ++k) a = fmaf(emb[k], t1w[o * time_dim + k], a);
+        hid[o] = mish_f(a);
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < time_dim; o += blockDim.x) {
+        float a = t3b[o];
+        for (int k = 0; k < 4 * time_dim; ++k) a = fmaf(hid[k], t3w[o * 4 * time_dim + k], a);
+        temb[o] = mish_f(a);  // every consumer applies Mish first (TimeMLP, blocks.py:64-67)
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < stride; c += blockDim.x) {
+        float a = tb[c];
+        for (int k = 0; k < time_dim; ++k) a = fmaf(temb[k], tw[(size_t)c * time_dim + k], a);
+        out[(size_t)blockIdx.x * stride + c] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host: load / build program
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int KC>
+static void launch_conv_t(const ConvP& p, hipStream_t s) {
+    dim3 grid((p.B + BM - 1) / BM, p.Lout * ((p.Cout + BN - 1) / BN));
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, KC>), grid, dim3(256), 0, s, p);
+}
+static int pick_kc(const ConvP& p) {
+    auto ok = [&](int kc) { return p.C1 % kc == 0 && (p.C2 == 0 || p.C2 % kc == 0); };
+    return ok(32) ? 32 : ok(16) ? 16 : 8;
+}
+static void launch_conv(const ConvP& p, hipStream_t s) {
+    const int kc = pick_kc(p);
+    const bool wide = (p.Cout % 64 == 0);
+    if (wide) {
+        if (kc == 32) launch_conv_t<64, 64, 32>(p, s);
+        else if (kc == 16) launch_conv_t<64, 64, 16>(p, s);
+        else launch_conv_t<64, 64, 8>(p, s);
+    } else {
+        if (kc == 32) launch_conv_t<128, 32, 32>(p, s);
+        else if (kc == 16) launch_conv_t<128, 32, 16>(p, s);
+        else launch_conv_t<128, 32, 8>(p, s);
+    }
+}
+static int launch_gn(const GnP& p, hipStream_t s) {
+    const int n = (p.C / 8) * p.L;
+    dim3 grid((p.B * 8 + 3) / 4);
+    if (n <= 128) hipLaunchKernelGGL((gn_mish_kernel<2>), grid, dim3(256), 0, s, p);
+    else if (n <= 256) hipLaunchKernelGGL((gn_mish_kernel<4>), grid, dim3(256), 0, s, p);
+    else if (n <= 512) hipLaunchKernelGGL((gn_mish_kernel<8>), grid, dim3(256), 0, s, p);
+    else {
+        set_error("GroupNorm group of %d elements exceeds the register-resident limit (512)", n);
+        return EDMP_ERR_ARG;
+    }
+    return EDMP_OK;
+}
+
+void unet_destroy(UNet* u) {
+    if (!u) return;
+    if (u->wpack) (void)hipFree(u->wpack);
+    if (u->tbias) (void)hipFree(u->tbias);
+    for (float* b : u->bufs) (void)hipFree(b);
+    delete u;
+}
+
+static inline int round8(int c) { return (c + 7) / 8 * 8; }
+
+struct Packer {
+    std::vector<float> host;
+    size_t add(size_t n) {
+        size_t o = host.size();
+        host.resize(o + ((n + 3) / 4) * 4, 0.0f);  // keep every tensor 16-byte aligned
+        return o;
+    }
+    // Conv1d weight (Cout, Cin, k) -> [tap][Cout][CinP]
+    size_t conv(const float* w, int cout, int cin, int k, int cinp) {
+        size_t o = add((size_t)k * cout * cinp);
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int t = 0; t < k; ++t) host[o + ((size_t)t * cout + co) * cinp + ci] = w[((size_t)co * cin + ci) * k + t];
+        return o;
+    }
+    // ConvTranspose1d weight (Cin, Cout, k) -> [tap][Cout][Cin]
+    size_t convT(const float* w, int cin, int cout, int k) {
+        size_t o = add((size_t)k * cout * cin);
+        for (int ci = 0; ci < cin; ++ci)
+            for (int co = 0; co < cout; ++co)
+                for (int t = 0; t < k; ++t) host[o + ((size_t)t * cout + co) * cin + ci] = w[((size_t)ci * cout + co) * k + t];
+        return o;
+    }
+    size_t vec(const float* v, int n) {
+        size_t o = add(n);
+        memcpy(&host[o], v, sizeof(float) * n);
+        return o;
+    }
+};
+
+struct BufPool {
+    std::vector<int> free_ids;
+    std::vector<int> pinned;  // never recycled (activation taps kept readable after a forward)
+    int n = 0;
+    int get() {
+        if (!free_ids.empty()) {
+            int i = free_ids.back();
+            free_ids.pop_back();
+            return i;
+        }
+        return n++;
+    }
+    void pin(int i) { pinned.push_back(i); }
+    void put(int i) {
+        for (int q : pinned)
+            if (q == i) return;
+        for (int q : free_ids)
+            if (q == i) return;
+        free_ids.push_back(i);
+    }
+};
+
+// Build-time tensor handle
+struct TH {
+    int buf;
+    int C, L;
+};
+
+}  // namespace edmp
+
+using namespace edmp;
+
+extern "C" int64_t edmp_unet_param_count(const edmp_unet_desc* desc) {
+    if (!desc || desc->n_levels < 2 || desc->n_levels > EDMP_MAX_LEVELS) return -1;
+    return inventory(*desc).total;
+}
+
+extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* params, int64_t n_params, int max_batch) {
+    EDMP_REQUIRE(ctx && desc && params, "edmp_unet_load: null argument");
+    EDMP_REQUIRE(desc->n_levels >= 2 && desc->n_levels <= EDMP_MAX_LEVELS, "n_levels out of range");
+    EDMP_REQUIRE(desc->input_dim >= 1 && desc->input_dim <= 8, "input_dim must be in 1..8");
+    EDMP_REQUIRE(desc->time_dim >= 4 && desc->time_dim % 2 == 0, "time_dim must be even");
+    EDMP_REQUIRE(max_batch >= 1, "max_batch must be positive");
+    for (int i = 0; i < desc->n_levels; ++i) EDMP_REQUIRE(desc->dims[i] % 8 == 0 && desc->dims[i] >= 8, "dims must be multiples of 8");
+    RawNet inv = inventory(*desc);
+    EDMP_REQUIRE(inv.total == n_params, "parameter blob has %lld floats, architecture needs %lld", (long long)n_params, (long long)inv.total);
+    EDMP_HIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->unet) {
+        unet_destroy(ctx->unet);
+        ctx->unet = nullptr;
+    }
+    UNet* u = new UNet();
+    u->desc = *desc;
+    u->max_batch = max_batch;
+    const int N = desc->horizon;
+    const int td = desc->time_dim;
+    std::vector<int> dm{desc->input_dim};
+    for (int i = 0; i < desc->n_levels; ++i) dm.push_back(desc->dims[i]);
+    const int nd = desc->n_levels;
+    const int CP0 = 8;  // padded input channels
+
+    Packer pk;
+    BufPool pool;
+    // program is first built with buffer ids / weight offsets, resolved to pointers after allocation
+    struct POp {
+        OpKind kind;
+        int src1, src2, C1, C2, Lin, Lout, ntaps, stride, pad, transposed, Cout;
+        size_t w, b;
+        int dst;
+        // gn
+        int y, L, C, res;
+        size_t gamma, beta;
+        int tb_off;
+        double fn, fe;
+    };
+    std::vector<POp> pops;
+    // concatenated time-MLP weights
+    std::vector<float> tw_all, tb_all;
+    int tb_cursor = 0;
+
+    auto valid_pairs = [](int Lin, int Lout, int k, int stride, int pad, bool tr) {
+        long cnt = 0;
+        for (int lo = 0; lo < Lout; ++lo)
+            for (int t = 0; t < k; ++t) {
+                if (!tr) {
+                    int li = lo * stride + t - pad;
+                    if (li >= 0 && li < Lin) ++cnt;
+                } else {
+                    int num = lo + pad - t;
+                    if (num >= 0 && num % stride == 0 && num / stride < Lin) ++cnt;
+                }
+            }
+        return cnt;
+    };
+    auto emit_conv = [&](TH a, const TH* a2, int cin_true, size_t w, size_t b, int Cout, int k, int stride, int pad, bool tr, int Lout) {
+        POp o{};
+        o.kind = OP_CONV;
+        o.src1 = a.buf;
+        o.C1 = a.C;
+        o.src2 = a2 ? a2->buf : -1;
+        o.C2 = a2 ? a2->C : 0;
+        o.Lin = a.L;
+        o.Lout = Lout;
+        o.ntaps = k;
+        o.stride = stride;
+        o.pad = pad;
+        o.transposed = tr;
+        o.Cout = Cout;
+        o.w = w;
+        o.b = b;
+        o.dst = pool.get();
+        // nominal FLOPs: what torch executes: conv 2*Lout*Cout*Cin*k ; convT 2*Lin*Cin*Cout*k (uncropped)
+        o.fn = tr ? 2.0 * a.L * cin_true * Cout * k : 2.0 * Lout * Cout * (double)cin_true * k;
+        o.fe = 2.0 * (double)valid_pairs(a.L, Lout, k, stride, pad, tr) * Cout * (double)(o.C1 + o.C2);
+        pops.push_back(o);
+        return TH{o.dst, Cout, Lout};
+    };
+    auto emit_gn = [&](TH y, size_t gamma, size_t beta, int res_buf, int tb_off) {
+        POp o{};
+        o.kind = OP_GN;
+        o.y = y.buf;
+        o.L = y.L;
+        o.C = y.C;
+        o.gamma = gamma;
+        o.beta = beta;
+        o.res = res_buf;
+        o.tb_off = tb_off;
+        pops.push_back(o);
+    };
+    int rcb_idx = 0;
+    auto emit_rcb = [&](TH x, const TH* x2) -> TH {
+        const RawRCB& r = inv.rcbs[rcb_idx++];
+        const int cin_store = x.C + (x2 ? x2->C : 0);
+        // conv1
+        size_t w1 = pk.conv(params + r.cb[0].w.off, r.cout, r.cin, 5, cin_store);
+        size_t b1 = pk.vec(params + r.cb[0].b.off, r.cout);
+        size_t g1 = pk.vec(params + r.cb[0].gw.off, r.cout), be1 = pk.vec(params + r.cb[0].gb.off, r.cout);
+        size_t w2 = pk.conv(params + r.cb[1].w.off, r.cout, r.cout, 5, r.cout);
+        size_t b2 = pk.vec(params + r.cb[1].b.off, r.cout);
+        size_t g2 = pk.vec(params + r.cb[1].gw.off, r.cout), be2 = pk.vec(params + r.cb[1].gb.off, r.cout);
+        int tb_off = tb_cursor;
+        tb_cursor += r.cout;
+        tw_all.insert(tw_all.end(), params + r.tw.off, params + r.tw.off + (size_t)r.cout * td);
+        tb_all.insert(tb_all.end(), params + r.tb.off, params + r.tb.off + r.cout);
+        TH y1 = emit_conv(x, x2, r.cin, w1, b1, r.cout, 5, 1, 2, false, x.L);
+        emit_gn(y1, g1, be1, -1, tb_off);
+        TH y2 = emit_conv(y1, nullptr, r.cout, w2, b2, r.cout, 5, 1, 2, false, x.L);
+        pool.put(y1.buf);
+        if (r.has_res) {
+            size_t wr = pk.conv(params + r.rw.off, r.cout, r.cin, 1, cin_store);
+            size_t br = pk.vec(params + r.rb.off, r.cout);
+            TH rr = emit_conv(x, x2, r.cin, wr, br, r.cout, 1, 1, 0, false, x.L);
+            emit_gn(y2, g2, be2, rr.buf, -1);
+            pool.put(rr.buf);
+        } else {
+            emit_gn(y2, g2, be2, x2 ? -2 : x.buf, -1);  // identity residual (blocks.py:151-152); -2 = unsupported concat
+        }
+        return y2;
+    };
+
+    TH x{pool.get(), CP0, N};
+    const int x_in_buf = x.buf;
+    std::vector<TH> skips;
+    struct TapRec { int which; int buf, C, L; };
+    std::vector<TapRec> tapr;
+    for (int i = 0; i < nd; ++i) {
+        TH a = emit_rcb(x, nullptr);
+        pool.put(x.buf);  // the block input is dead once both consumers (conv1, residual) are emitted
+        TH b = emit_rcb(a, nullptr);
+        pool.put(a.buf);
+        skips.push_back(b);
+        if (i != nd - 1) {
+            size_t w = pk.conv(params + inv.down_w[i].off, dm[i + 1], dm[i + 1], 3, dm[i + 1]);
+            size_t bb = pk.vec(params + inv.down_b[i].off, dm[i + 1]);
+            int Lout = (b.L - 1) / 2 + 1;
+            x = emit_conv(b, nullptr, dm[i + 1], w, bb, dm[i + 1], 3, 2, 1, false, Lout);
+        } else {
+            x = b;
+        }
+        tapr.push_back({i, x.buf, x.C, x.L});
+        pool.pin(x.buf);
+    }
+    {
+        // middle: input is skips.back() (same buffer, must stay alive for the up path)
+        TH a = emit_rcb(x, nullptr);
+        TH b = emit_rcb(a, nullptr);
+        pool.put(a.buf);
+        x = b;
+        tapr.push_back({100, x.buf, x.C, x.L});
+        pool.pin(x.buf);
+    }
+    for (int j = 0, i = nd; i > 1; --i, ++j) {
+        TH sk = skips.back();
+        skips.pop_back();
+        EDMP_REQUIRE(sk.L == x.L && sk.C == x.C, "skip/upsample shape mismatch at up level %d (L %d vs %d)", j, sk.L, x.L);
+        TH a = emit_rcb(x, &sk);
+        pool.put(x.buf);
+        pool.put(sk.buf);
+        TH b = emit_rcb(a, nullptr);
+        pool.put(a.buf);
+        size_t w = pk.convT(params + inv.up_w[j].off, dm[i - 1], dm[i - 1], 4);
+        size_t bb = pk.vec(params + inv.up_b[j].off, dm[i - 1]);
+        int Lout = 2 * b.L;
+        if (Lout == 8 || Lout == 14 || Lout == 26) Lout -= 1;  // crop rule, temporalunet.py:70-71
+        x = emit_conv(b, nullptr, dm[i - 1], w, bb, dm[i - 1], 4, 2, 1, true, Lout);
+        pool.put(b.buf);
+        tapr.push_back({200 + j, x.buf, x.C, x.L});
+        pool.pin(x.buf);
+    }
+    EDMP_REQUIRE(x.L == N, "decoder output length %d != horizon %d", x.L, N);
+    // final Conv1dBlock + 1x1 head
+    {
+        size_t w = pk.conv(params + inv.final_cb.w.off, dm[1], dm[1], 5, dm[1]);
+        size_t b = pk.vec(params + inv.final_cb.b.off, dm[1]);
+        size_t g = pk.vec(params + inv.final_cb.gw.off, dm[1]), be = pk.vec(params + inv.final_cb.gb.off, dm[1]);
+        TH y = emit_conv(x, nullptr, dm[1], w, b, dm[1], 5, 1, 2, false, N);
+        emit_gn(y, g, be, -1, -1);
+        pool.put(x.buf);
+        x = y;
+    }
+    size_t hw = pk.vec(params + inv.final_w.off, desc->input_dim * dm[1]);
+    size_t hb = pk.vec(params + inv.final_b.off, desc->input_dim);
+    const double head_flops = 2.0 * N * desc->input_dim * dm[1];
+
+    // raw time-embedding weights for the table kernel
+    size_t o_t1w = pk.vec(params + inv.t1w.off, 4 * td * td), o_t1b = pk.vec(params + inv.t1b.off, 4 * td);
+    size_t o_t3w = pk.vec(params + inv.t3w.off, 4 * td * td), o_t3b = pk.vec(params + inv.t3b.off, td);
+    size_t o_tw = pk.vec(tw_all.data(), (int)tw_all.size()), o_tb = pk.vec(tb_all.data(), (int)tb_all.size());
+    u->tb_stride = tb_cursor;
+
+    for (auto& o : pops) EDMP_REQUIRE(!(o.kind == OP_GN && o.res == -2), "identity residual over a channel concat is not supported");
+    // allocate
+    size_t max_lc = (size_t)N * CP0;
+    for (auto& o : pops)
+        if (o.kind == OP_CONV) max_lc = std::max(max_lc, (size_t)o.Lout * o.Cout);
+    u->buf_cap = max_lc * (size_t)max_batch;
+    if (hipMalloc((void**)&u->wpack, pk.host.size() * sizeof(float)) != hipSuccess) {
+        unet_destroy(u);
+        set_error("hipMalloc of %zu weight bytes failed", pk.host.size() * sizeof(float));
+        return EDMP_ERR_HIP;
+    }
+    EDMP_HIP_CHECK(hipMemcpy(u->wpack, pk.host.data(), pk.host.size() * sizeof(float), hipMemcpyHostToDevice));
+    for (int i = 0; i < pool.n; ++i) {
+        float* p = nullptr;
+        if (hipMalloc((void**)&p, u->buf_cap * sizeof(float)) != hipSuccess) {
+            unet_destroy(u);
+            set_error("hipMalloc of activation buffer %d (%zu bytes) failed", i, u->buf_cap * sizeof(float));
+            return EDMP_ERR_HIP;
+        }
+        u->bufs.push_back(p);
+    }
+    EDMP_HIP_CHECK(hipMalloc((void**)&u->tbias, (size_t)desc->T * u->tb_stride * sizeof(float)));
+    {
+        size_t sm = (size_t)(6 * td) * sizeof(float);
+        hipLaunchKernelGGL(time_table_kernel, dim3(desc->T), dim3(256), sm, ctx->stream, u->wpack + o_t1w, u->wpack + o_t1b,
+                           u->wpack + o_t3w, u->wpack + o_t3b, u->wpack + o_tw, u->wpack + o_tb, u->tbias, td, u->tb_stride);
+        EDMP_HIP_CHECK(hipGetLastError());
+        EDMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    // resolve program
+    for (auto& o : pops) {
+        Op op{};
+        op.kind = o.kind;
+        op.tb_off = -1;
+        if (o.kind == OP_CONV) {
+            ConvP& c = op.cv;
+            c.src1 = u->bufs[o.src1];
+            c.src2 = o.src2 >= 0 ? u->bufs[o.src2] : nullptr;
+            c.C1 = o.C1;
+            c.C2 = o.C2;
+            c.Lin = o.Lin;
+            c.Lout = o.Lout;
+            c.ntaps = o.ntaps;
+            c.stride = o.stride;
+            c.pad = o.pad;
+            c.transposed = o.transposed;
+            c.W = u->wpack + o.w;
+            c.bias = u->wpack + o.b;
+            c.dst = u->bufs[o.dst];
+            c.Cout = o.Cout;
+            op.flops_nominal = o.fn;
+            op.flops_exec = o.fe;
+            u->flops_nominal += o.fn;
+            u->flops_exec += o.fe;
+        } else {
+            GnP& g = op.gn;
+            g.y = u->bufs[o.y];
+            g.gamma = u->wpack + o.gamma;
+            g.beta = u->wpack + o.beta;
+            g.add_res = o.res >= 0 ? u->bufs[o.res] : nullptr;
+            g.add_tbias = nullptr;
+            g.L = o.L;
+            g.C = o.C;
+            op.tb_off = o.tb_off;
+        }
+        u->prog.push_back(op);
+    }
+    u->flops_nominal += head_flops;
+    u->flops_exec += head_flops;
+    u->x_in = u->bufs[x_in_buf];
+    u->h_last = u->bufs[x.buf];
+    u->head_w = u->wpack + hw;
+    u->head_b = u->wpack + hb;
+    u->head_cin = dm[1];
+    for (auto& t : tapr) u->taps.push_back({t.which, u->bufs[t.buf], t.C, t.L});
+    ctx->unet = u;
+    return EDMP_OK;
+}
+
+namespace edmp {
+// shared with sampler.hip: run the forward on the context's stream
+int unet_forward_impl(edmp_ctx* ctx, const float* x_dev, int B, int t, float* eps_dev) {
+    UNet* u = ctx->unet;
+    EDMP_REQUIRE(u, "edmp_unet_load has not been called");
+    EDMP_REQUIRE(B >= 1 && B <= u->max_batch, "batch %d outside 1..max_batch=%d", B, u->max_batch);
+    EDMP_REQUIRE(t >= 1 && t <= u->desc.T, "t=%d outside 1..T=%d", t, u->desc.T);
+    hipStream_t s = ctx->stream;
+    const int N = u->desc.horizon, C = u->desc.input_dim;
+    {
+        int total = B * N * 8;
+        hipLaunchKernelGGL(pack_input_kernel, dim3((total + 255) / 256), dim3(256), 0, s, x_dev, u->x_in, B, C, N, 8);
+    }
+    const float* trow = u->tbias + (size_t)(t - 1) * u->tb_stride;
+    Prof& pf = ctx->prof;
+    for (const Op& op : u->prog) {
+        if (op.kind == OP_CONV) {
+            ConvP p = op.cv;
+            p.B = B;
+            if (pf.on) {
+                std::pair<hipEvent_t, hipEvent_t> ev;
+                if (!pf.pool.empty()) {
+                    ev = pf.pool.back();
+                    pf.pool.pop_back();
+                } else {
+                    EDMP_HIP_CHECK(hipEventCreate(&ev.first));
+                    EDMP_HIP_CHECK(hipEventCreate(&ev.second));
+                }
+                EDMP_HIP_CHECK(hipEventRecord(ev.first, s));
+                launch_conv(p, s);
+                EDMP_HIP_CHECK(hipEventRecord(ev.second, s));
+                pf.pending.push_back(ev);
+            } else {
+                launch_conv(p, s);
+            }
+        } else {
+            GnP g = op.gn;
+            g.B = B;
+            g.add_tbias = op.tb_off >= 0 ? trow + op.tb_off : nullptr;
+            int rc = launch_gn(g, s);
+            if (rc) return rc;
+        }
+    }
+    hipLaunchKernelGGL(head_1x1_kernel, dim3((B * N + 255) / 256), dim3(256), 0, s, u->h_last, u->head_w, u->head_b, eps_dev, B, N,
+                       u->head_cin, C);
+    EDMP_HIP_CHECK(hipGetLastError());
+    return EDMP_OK;
+}
+}  // namespace edmp
+
+extern "C" int edmp_unet_forward_dev(edmp_ctx* ctx, const float* x_dev, int B, int t, float* eps_dev) {
+    EDMP_REQUIRE(ctx && x_dev && eps_dev, "edmp_unet_forward_dev: null argument");
+    EDMP_HIP_CHECK(hipSetDevice(ctx->device));
+    return unet_forward_impl(ctx, x_dev, B, t, eps_dev);
+}
+
+extern "C" int edmp_unet_read_activation_dev(edmp_ctx* ctx, int which, int B, float* out_dev, int* C_out, int* L_out) {
+    EDMP_REQUIRE(ctx && ctx->unet && out_dev, "edmp_unet_read_activation_dev: null argument / no model");
+    for (auto& t : ctx->unet->taps)
+        if (t.which == which) {
+            int total = B * t.C * t.L;
+            hipLaunchKernelGGL(unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, t.p, out_dev, B, t.L, t.C);
+            EDMP_HIP_CHECK(hipGetLastError());
+            if (C_out) *C_out = t.C;
+            if (L_out) *L_out = t.L;
+            return EDMP_OK;
+        }
+    set_error("no activation tap %d", which);
+    return EDMP_ERR_ARG;
+}
+
+extern "C" int edmp_unet_flops(edmp_ctx* ctx, double* nominal, double* executed) {
+    EDMP_REQUIRE(ctx && ctx->unet, "no model loaded");
+    if (nominal) *nominal = ctx->unet->flops_nominal;
+    if (executed) *executed = ctx->unet->flops_exec;
+    return EDMP_OK;
+}

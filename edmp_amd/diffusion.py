@@ -1,0 +1,128 @@
+"""Diffusion — host-side mirror of the reference sampler object (diffusion/diffusion.py:8-356).  The reverse loop
+(`denoise_guided`) runs device-resident in libedmp_hip.so (edmp_amd/csrc/sampler.hip): one host call per scene."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi, franka
+from .runtime import get_context, ptr
+
+
+def draw_noise(T: int, batch_size: int, num_channels: int, traj_len: int) -> np.ndarray:
+    """(T+1, B, C, N) f64 from the GLOBAL NumPy RandomState in the reference's call order: one
+    ``multivariate_normal(0, I_N, size=(B, C))`` for X_T (diffusion.py:303) then one per step (diffusion.py:126).
+    With an identity covariance that call consumes the stream exactly like ``standard_normal((B, C, N))``
+    (pinned by tests/test_host.py), so all draws are made in one vectorised call."""
+    return np.random.standard_normal((T + 1, batch_size, num_channels, traj_len))
+
+
+class Diffusion:
+    """Same constructor / method signatures as the reference ``Diffusion(T, device, variance_thresh=0.02)``."""
+
+    def __init__(self, T, device, variance_thresh=0.02):
+        self.T = int(T)
+        self.variance_thresh = float(variance_thresh)
+        self.ctx = get_context(device)
+        self.device = self.ctx.device
+        self.ctx.ensure_sampler(self.T, self.variance_thresh)
+        self.beta = np.zeros(self.T)
+        self.alpha = np.zeros(self.T)
+        self.alpha_bar = np.zeros(self.T)
+        _capi.check(self.ctx.lib.edmp_sampler_read_schedule(self.ctx.h, _capi.as_pd(self.beta), _capi.as_pd(self.alpha), _capi.as_pd(self.alpha_bar)))
+
+    def schedule_variance(self, thresh=0.02):
+        return self.beta.copy()
+
+    # ---- single pieces (reference API) ------------------------------------------------------------------------
+    def p_sample_using_posterior(self, xt, t, eps, z=None):
+        """diffusion.py:116-135.  Draws z from the global NumPy RNG like the reference unless ``z`` is given."""
+        ctx = self.ctx
+        ctx.ensure_sampler(self.T, self.variance_thresh)
+        b, c, n = xt.shape
+        if z is None:
+            z = np.random.standard_normal((b, c, n))
+        X = ctx.to_dev(np.asarray(xt, dtype=np.float64), torch.float64).clone()
+        e = ctx.to_dev(eps, torch.float32)
+        zd = ctx.to_dev(np.asarray(z, dtype=np.float64), torch.float64)
+        _capi.check(ctx.lib.edmp_psample_dev(ctx.h, ptr(X), ptr(e), ptr(zd), b, c, n, int(t), 1), "edmp_psample_dev")
+        return ctx.to_host(X)
+
+    def clip_joints(self, joints):
+        lo, hi = franka.joint_limits()
+        return np.clip(joints, lo[np.newaxis, :, np.newaxis], hi[np.newaxis, :, np.newaxis])
+
+    # ---- the loop ----------------------------------------------------------------------------------------------
+    def _prepare(self, model, guide, batch_size, guidance_schedule):
+        ctx = self.ctx
+        if model.ctx is not ctx or (guide is not None and guide.ctx is not ctx):
+            raise _capi.EdmpError("model, guide and diffuser must live on the same GPU")
+        ctx.ensure_sampler(self.T, self.variance_thresh)
+        model._bind()
+        if guide is not None:
+            guide._bind()
+            if guide.batch_size != batch_size:
+                raise ValueError(f"guide was built for batch {guide.batch_size}, denoise_guided called with {batch_size}")
+            guide._set_rows(guidance_schedule if guidance_schedule is not None else guide._sched)
+
+    def denoise_guided(self, model, guide, traj_len, num_channels, guidance_schedule, batch_size=1, start=None, goal=None,
+                       condition=True, benchmarking=False, *, noise=None, t_stop=0, zero_row0=True, return_device=False):
+        """diffusion.py:300-356.  ``noise``: optional pre-drawn (T+1,B,C,N) f64 ndarray / device tensor (default:
+        drawn from the global NumPy RNG in the reference's order).  Returns (B,C,N) f64 ndarray (a fresh copy)."""
+        if not condition:
+            raise NotImplementedError("the reference driver always conditions on start/goal (infer_serial.py:139)")
+        ctx = self.ctx
+        self._prepare(model, guide, batch_size, guidance_schedule)
+        if noise is None:
+            noise = draw_noise(self.T, batch_size, num_channels, traj_len)
+        nd = noise if (isinstance(noise, torch.Tensor) and noise.is_cuda) else ctx.to_dev(noise, torch.float64)
+        if tuple(nd.shape) != (self.T + 1, batch_size, num_channels, traj_len) or nd.dtype != torch.float64:
+            raise ValueError(f"noise must be f64 {(self.T + 1, batch_size, num_channels, traj_len)}, got {tuple(nd.shape)} {nd.dtype}")
+        s = np.ascontiguousarray(np.asarray(start, dtype=np.float64).reshape(-1))
+        g = np.ascontiguousarray(np.asarray(goal, dtype=np.float64).reshape(-1))
+        out = ctx.empty((batch_size, num_channels, traj_len), torch.float64)
+        _capi.check(
+            ctx.lib.edmp_denoise_guided_dev(ctx.h, ptr(nd), batch_size, _capi.as_pd(s), _capi.as_pd(g), 1 if guide is not None else 0, int(t_stop),
+                                            1 if zero_row0 else 0, ptr(out)),
+            "edmp_denoise_guided_dev",
+        )
+        if return_device:
+            return out
+        return ctx.to_host(out)
+
+    def denoise(self, model, traj_len, num_channels, start=None, goal=None, condition=True, *, batch_size=1, noise=None):
+        """diffusion.py:253-278 (unguided), batched; returns X[0] like the reference when batch_size == 1."""
+        X = self.denoise_guided(model, None, traj_len, num_channels, None, batch_size=batch_size, start=start, goal=goal, condition=condition, noise=noise)
+        return X[0] if batch_size == 1 else X
+
+    def denoise_step(self, model, guide, X, z, t, start, goal, guidance_schedule=None, zero_row0=True, allreduce=None):
+        """One teacher-forced reverse step on host arrays: returns dict(eps, x_post, grad (mixed, or None), x_out).
+        ``allreduce(tensor)``: optional in-place sum over ranks of the device scalar sum(g^2) (multi-GPU)."""
+        ctx = self.ctx
+        B, Cc, N = X.shape
+        self._prepare(model, guide, B, guidance_schedule)
+        Xd = ctx.to_dev(np.asarray(X, dtype=np.float64), torch.float64).clone()
+        zd = ctx.to_dev(np.asarray(z, dtype=np.float64), torch.float64)
+        s = np.ascontiguousarray(np.asarray(start, dtype=np.float64).reshape(-1))
+        g = np.ascontiguousarray(np.asarray(goal, dtype=np.float64).reshape(-1))
+        eps = ctx.empty((B, Cc, N), torch.float32)
+        xpost = ctx.empty((B, Cc, N), torch.float64)
+        grad = ctx.empty((B, Cc, N - 2), torch.float64)
+        _capi.check(ctx.lib.edmp_step_a_dev(ctx.h, ptr(Xd), ptr(zd), B, int(t), _capi.as_pd(s), _capi.as_pd(g), 1 if zero_row0 else 0, ptr(eps), ptr(xpost)), "edmp_step_a_dev")
+        guided = (t % 2) < 1 and t >= 5
+        if guided and allreduce is not None:
+            ctx.sync()
+            allreduce(self.sumsq_tensor())
+        _capi.check(ctx.lib.edmp_step_b_dev(ctx.h, ptr(Xd), B, int(t), _capi.as_pd(s), _capi.as_pd(g), ptr(grad)), "edmp_step_b_dev")
+        return dict(eps=ctx.to_host(eps), x_post=ctx.to_host(xpost), grad=ctx.to_host(grad) if guided else None, x_out=ctx.to_host(Xd))
+
+    def sumsq_tensor(self) -> torch.Tensor:
+        """zero-copy f64 view of the device scalar holding sum(g^2) of the last guided step."""
+        p = self.ctx.lib.edmp_sumsq_ptr_dev(self.ctx.h)
+
+        class _Holder:
+            __cuda_array_interface__ = {"shape": (1,), "typestr": "<f8", "data": (int(p), False), "version": 2}
+
+        return torch.as_tensor(_Holder(), device=self.ctx.device)

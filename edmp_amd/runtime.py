@@ -1,0 +1,91 @@
+"""Per-GPU context: owns the libedmp_hip handle, a torch stream for copies + kernels, and tracks which model / guide
+object is currently bound.  PyTorch is plumbing here (device memory, streams, torch.distributed) — all arithmetic of
+the hot path runs in libedmp_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+
+_contexts: dict = {}
+
+
+def _device_index(device) -> int:
+    if isinstance(device, int):
+        return device
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise _capi.EdmpError(
+            f"edmp_amd runs on an MI355X only (device={device!r}).  There is no CPU path: use device='cuda:<i>'."
+        )
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+class Context:
+    def __init__(self, index: int):
+        if not torch.cuda.is_available():
+            raise _capi.EdmpError("no GPU visible to torch: edmp_amd needs an MI355X (gfx950); there is no CPU fallback")
+        self.lib = _capi.load()
+        self.index = index
+        self.device = torch.device("cuda", index)
+        h = C.c_void_p()
+        _capi.check(self.lib.edmp_ctx_create(index, C.byref(h)), "edmp_ctx_create")
+        self.h = h
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.Stream(device=self.device)
+        _capi.check(self.lib.edmp_ctx_set_stream(self.h, C.c_void_p(self.stream.cuda_stream)), "edmp_ctx_set_stream")
+        self.bound_model = None
+        self.bound_guide = None
+        self.sampler_T = None
+
+    # ---- helpers ---------------------------------------------------------------------------------------------
+    def to_dev(self, arr, dtype) -> torch.Tensor:
+        """host ndarray / tensor -> contiguous device tensor on this context's stream."""
+        with torch.cuda.stream(self.stream):
+            if isinstance(arr, torch.Tensor):
+                t = arr.to(device=self.device, dtype=dtype).contiguous()
+            else:
+                t = torch.from_numpy(np.ascontiguousarray(arr)).to(dtype=dtype).to(self.device)
+        return t
+
+    def empty(self, shape, dtype) -> torch.Tensor:
+        with torch.cuda.stream(self.stream):
+            return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def sync(self):
+        _capi.check(self.lib.edmp_ctx_synchronize(self.h), "edmp_ctx_synchronize")
+
+    def to_host(self, t: torch.Tensor) -> np.ndarray:
+        with torch.cuda.stream(self.stream):
+            out = t.cpu()
+        self.stream.synchronize()
+        return out.numpy()
+
+    def ensure_sampler(self, T: int, variance_thresh: float = 0.02):
+        key = (T, variance_thresh)
+        if self.sampler_T != key:
+            _capi.check(self.lib.edmp_sampler_init(self.h, int(T), float(variance_thresh)), "edmp_sampler_init")
+            self.sampler_T = key
+
+    def prof(self, on: bool):
+        _capi.check(self.lib.edmp_prof_enable(self.h, 1 if on else 0))
+
+    def prof_read(self, reset=True):
+        ms = C.c_double()
+        n = C.c_int64()
+        _capi.check(self.lib.edmp_prof_read(self.h, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
+
+
+def get_context(device) -> Context:
+    idx = _device_index(device)
+    if idx not in _contexts:
+        _contexts[idx] = Context(idx)
+    return _contexts[idx]
+
+
+def ptr(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,123 @@
+"""TemporalUNet — host-side mirror of the reference denoiser object (diffusion/models/temporalunet.py:9-100) whose
+forward runs in libedmp_hip.so (edmp_amd/csrc/unet.hip)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _capi, weights
+from .runtime import get_context, ptr
+
+
+class TemporalUNet:
+    """Same constructor / call signature as the reference:
+
+        net = TemporalUNet(model_name, input_dim, time_dim, device, dims=(32, 64, 128, 256))
+        eps = net(x, t)          # x (B, input_dim, 50) f32, t (1,) f32  ->  (B, input_dim, 50) f32 tensor on `device`
+        net.train(False)
+
+    Reference semantics kept: if the directory ``model_name`` does not exist it is created and the network keeps
+    a random initialisation (temporalunet.py:39-41), otherwise ``weights_latest.pt`` is loaded (:42-43, :88-92).
+    Extras (keyword only): ``state_dict`` (name -> array, overrides disk), ``seed`` for the random init,
+    ``max_batch`` (activation workspace size), ``horizon`` (50), ``T`` (size of the precomputed time-bias table).
+    """
+
+    def __init__(self, model_name, input_dim, time_dim, device, dims=(32, 64, 128, 256), *, state_dict=None, seed=0,
+                 max_batch=1024, horizon=50, T=255):
+        self.model_name = model_name
+        self.input_dim, self.time_dim, self.dims = int(input_dim), int(time_dim), tuple(int(d) for d in dims)
+        self.horizon, self.T = int(horizon), int(T)
+        self.max_batch = int(max_batch)
+        self.ctx = get_context(device)
+        self.device = self.ctx.device
+        if state_dict is None:
+            if model_name is not None and os.path.exists(model_name):
+                state_dict = weights.load_checkpoint_dir(model_name)
+                self.losses = np.load(os.path.join(model_name, "losses.npy")) if os.path.exists(os.path.join(model_name, "losses.npy")) else np.array([])
+                print("Loaded Model at " + str(self.losses.size) + " epochs")
+            else:
+                if model_name is not None:
+                    os.mkdir(model_name)
+                self.losses = np.array([])
+                state_dict = weights.init_state_dict(seed, self.input_dim, self.time_dim, self.dims)
+        shapes = weights.unet_param_shapes(self.input_dim, self.time_dim, self.dims)
+        missing = [k for k in shapes if k not in state_dict]
+        if missing:
+            raise KeyError(f"state dict lacks {len(missing)} tensors, e.g. {missing[:3]}")
+        flat = []
+        for k, shp in shapes.items():
+            v = np.asarray(state_dict[k].detach().cpu().numpy() if isinstance(state_dict[k], torch.Tensor) else state_dict[k], dtype=np.float32)
+            if tuple(v.shape) != tuple(shp):
+                raise ValueError(f"{k}: shape {tuple(v.shape)} != expected {tuple(shp)}")
+            flat.append(v.reshape(-1))
+        self._flat = np.ascontiguousarray(np.concatenate(flat))
+        self._bind()
+
+    def _desc(self):
+        d = _capi.UNetDesc()
+        d.input_dim, d.time_dim, d.n_levels = self.input_dim, self.time_dim, len(self.dims)
+        for i, v in enumerate(self.dims):
+            d.dims[i] = v
+        d.horizon, d.T = self.horizon, self.T
+        return d
+
+    def _bind(self):
+        ctx = self.ctx
+        if ctx.bound_model is self:
+            return
+        d = self._desc()
+        n = ctx.lib.edmp_unet_param_count(C.byref(d))
+        if n != self._flat.size:
+            raise _capi.EdmpError(f"parameter count mismatch: python {self._flat.size}, library {n}")
+        _capi.check(ctx.lib.edmp_unet_load(ctx.h, C.byref(d), _capi.as_pf(self._flat), self._flat.size, self.max_batch), "edmp_unet_load")
+        ctx.bound_model = self
+
+    def train(self, mode=True):
+        return self
+
+    def eval(self):
+        return self
+
+    def forward(self, x, t):
+        ctx = self.ctx
+        self._bind()
+        tt = float(t.reshape(-1)[0]) if isinstance(t, (torch.Tensor, np.ndarray)) else float(t)
+        ti = int(round(tt))
+        if ti != tt:
+            raise ValueError(f"t must be an integer diffusion step (got {tt}); the time-bias table is precomputed for t=1..{self.T}")
+        xd = ctx.to_dev(x, torch.float32)
+        if xd.dim() != 3 or xd.shape[1] != self.input_dim or xd.shape[2] != self.horizon:
+            raise ValueError(f"x must be (B, {self.input_dim}, {self.horizon}), got {tuple(xd.shape)}")
+        eps = ctx.empty(xd.shape, torch.float32)
+        _capi.check(ctx.lib.edmp_unet_forward_dev(ctx.h, ptr(xd), xd.shape[0], ti, ptr(eps)), "edmp_unet_forward_dev")
+        ctx.sync()
+        return eps
+
+    __call__ = forward
+
+    def activation(self, which: int, B: int):
+        """(B, C, L) f32 copy of an internal activation of the LAST forward (parity/debug)."""
+        ctx = self.ctx
+        buf = ctx.empty((B * 4096,), torch.float32)
+        c, l = C.c_int(), C.c_int()
+        _capi.check(ctx.lib.edmp_unet_read_activation_dev(ctx.h, which, B, ptr(buf), C.byref(c), C.byref(l)))
+        ctx.sync()
+        return buf[: B * c.value * l.value].reshape(B, c.value, l.value)
+
+    def flops_per_trajectory(self):
+        self._bind()
+        a, b = C.c_double(), C.c_double()
+        _capi.check(self.ctx.lib.edmp_unet_flops(self.ctx.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def save(self):
+        sd = {}
+        off = 0
+        for k, shp in weights.unet_param_shapes(self.input_dim, self.time_dim, self.dims).items():
+            n = int(np.prod(shp))
+            sd[k] = self._flat[off : off + n].reshape(shp)
+            off += n
+        weights.save_checkpoint_dir(self.model_name, sd)

@@ -1,0 +1,140 @@
+/* edmp_hip.h — C-ABI of libedmp_hip.so: the MI355X (gfx950) implementation of EDMP's guided reverse-diffusion
+ * sampler hot path.  This is the drop-in boundary: plain pointers and sizes, opaque context handle,
+ * int status return (0 = ok, <0 = error; text via edmp_last_error()).  No torch / Python types.
+ *
+ * The reference (vishal-2000/EDMP) has no FFI: the path is reached through duck-typed Python objects created in
+ * infer_serial.py:43-51,112 and passed to Diffusion.denoise_guided (infer_serial.py:134-143).  Each entry point
+ * below names the reference method(s) it replaces (paths relative to the reference checkout); the Python binding
+ * that exposes the reference's signatures on top of this ABI is edmp_amd/_capi.py (ctypes), see INTEGRATION.md.
+ *
+ * Conventions: pointers suffixed _dev are device (HBM) addresses on the context's GPU, all others are host
+ * addresses read synchronously before the call returns.  All device work is stream-ordered on the context's
+ * stream (edmp_ctx_set_stream); calls return without synchronising unless stated.  One host thread per context.
+ * Trajectory tensors use the reference's layout (B, C=7, N) row-major, "f64" = IEEE double, "f32" = float.
+ */
+#ifndef EDMP_HIP_H
+#define EDMP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EDMP_OK 0
+#define EDMP_ERR_ARG (-1)
+#define EDMP_ERR_HIP (-2)
+#define EDMP_ERR_STATE (-3)
+
+#define EDMP_MAX_LEVELS 8
+#define EDMP_N_JOINTS 7
+#define EDMP_N_LINKS 9
+#define EDMP_MAX_OBSTACLES 64
+
+typedef struct edmp_ctx edmp_ctx;
+
+/* ---- context ------------------------------------------------------------------------------------------- */
+const char* edmp_last_error(void);
+int edmp_version(void);
+/* one context per GPU; creates its own stream */
+int edmp_ctx_create(int device, edmp_ctx** out);
+void edmp_ctx_destroy(edmp_ctx* ctx);
+/* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the context's own stream */
+int edmp_ctx_set_stream(edmp_ctx* ctx, void* hip_stream);
+int edmp_ctx_synchronize(edmp_ctx* ctx);
+
+/* ---- denoiser: TemporalUNet -------------------------------------------------------------------------- */
+/* replaces TemporalUNet.__init__/load (diffusion/models/temporalunet.py:11-45, 88-92) */
+typedef struct edmp_unet_desc {
+    int32_t input_dim;             /* 7 */
+    int32_t time_dim;              /* 32 */
+    int32_t n_levels;              /* len(dims), 6 */
+    int32_t dims[EDMP_MAX_LEVELS]; /* (32,64,128,256,512,512) */
+    int32_t horizon;               /* N = 50 */
+    int32_t T;                     /* number of diffusion steps the time-bias table covers (255) */
+} edmp_unet_desc;
+
+/* number of floats of the flat parameter blob for `desc` (all state-dict tensors, in state-dict order, each in
+ * its native torch layout, concatenated) */
+int64_t edmp_unet_param_count(const edmp_unet_desc* desc);
+/* upload + repack weights, precompute the (T x sum Cout) time-bias table, allocate activations for max_batch */
+int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* params, int64_t n_params, int max_batch);
+/* replaces TemporalUNet.forward (temporalunet.py:47-76): x (B,C,N) f32, integer t in [1,T] -> eps (B,C,N) f32 */
+int edmp_unet_forward_dev(edmp_ctx* ctx, const float* x_dev, int B, int t, float* eps_dev);
+/* debug/parity: copy an internal activation, converted to the reference layout (B, C, L) f32.
+ * which: 0..n_levels-1 = output of down level i, 100 = middle block, 200+i = output of up level i */
+int edmp_unet_read_activation_dev(edmp_ctx* ctx, int which, int B, float* out_dev, int* C_out, int* L_out);
+/* algorithmic FLOPs of one forward per trajectory: (a) nominal = every conv tap counted, the reference's own
+ * arithmetic (SURVEY.md §8d, 187 339 904 for the full net); (b) executed = taps that fall in the zero padding are
+ * skipped by the kernels */
+int edmp_unet_flops(edmp_ctx* ctx, double* nominal, double* executed);
+
+/* ---- guide: IntersectionVolumeGuide -------------------------------------------------------------------- */
+/* replaces IntersectionVolumeGuide.__init__/define_link_information/define_obstacles
+ * (lib/guide.py:13-43, 243-342, 118-158).  obstacle_config (no,10) f64 rows [xyz, quat xyzw, full extents];
+ * clearance/expansion (G,T) f64 = one row per distinct guide class; builds the device table of inflated obstacle
+ * AABBs for every (class, t in 0..T).  link_half_extents (9,3) f32; dh (7,4) f32 rows [a,d,cos(alpha),sin(alpha)];
+ * static_frames (9,3,4) f32. */
+int edmp_scene_set(edmp_ctx* ctx, const double* obstacle_config, int n_obstacles, const double* clearance,
+                   const double* expansion, int n_classes, int T, const float* link_half_extents, const float* dh,
+                   const float* static_frames);
+/* per-row parameters (infer_serial.py:56-91): class index, method (0 iv / 1 sv), grad_norm (0/1),
+ * guidance_schedule (B,T) f64 */
+int edmp_rows_set(edmp_ctx* ctx, const int32_t* row_class, const float* method, const double* grad_norm,
+                  const double* guidance_schedule, int B, int T);
+/* copy the obstacle AABB table entry (class, t): out (no, 6) f32 = [min xyz, max xyz] (parity checks) */
+int edmp_scene_read_aabbs(edmp_ctx* ctx, int cls, int t, float* out_host);
+/* replaces IntersectionVolumeGuide.cost (lib/guide.py:354-395): joints (n,7,L) f32 -> volumes (n,L,9*no) f32.
+ * row r uses class row_class[r] if use_row_class else class 0; t = 0 means no inflation. */
+int edmp_guide_cost_dev(edmp_ctx* ctx, const float* joints_dev, int n, int L, int t, int use_row_class,
+                        float* volumes_dev);
+/* replaces swept_volume_cost (lib/guide.py:473-537): joints (n,7,L) f32 interior waypoints, start/goal (7,) f32
+ * -> volumes (n, L+1, 9*no) f32 */
+int edmp_guide_swept_cost_dev(edmp_ctx* ctx, const float* joints_dev, int n, int L, int t, int use_row_class,
+                              const float* start, const float* goal, float* volumes_dev);
+/* replaces get_gradient (lib/guide.py:597-635) incl. the whole-batch norm mixing: joints (B,7,L) f64 (already
+ * clipped) -> gradient (B,7,L) f64.  sumsq_dev (optional, may be NULL) receives sum(g^2) (f64) before mixing. */
+int edmp_guide_gradient_dev(edmp_ctx* ctx, const double* joints_dev, int B, int L, const double* start,
+                            const double* goal, int t, double* grad_dev, double* sumsq_dev);
+/* replaces the volume part of choose_best_trajectory (lib/guide.py:637-653): X (B,7,N) f64 -> per-row t=0 swept
+ * volume (B,) f32; the argmin (first on ties) is written to *best_index (host, synchronises) if not NULL */
+int edmp_row_swept_volumes_dev(edmp_ctx* ctx, const double* X_dev, int B, int N, const double* start,
+                               const double* goal, float* volumes_dev, int* best_index);
+
+/* ---- sampler: Diffusion ------------------------------------------------------------------------------ */
+/* replaces Diffusion.__init__/schedule_variance (diffusion/diffusion.py:10-20, 37-49) */
+int edmp_sampler_init(edmp_ctx* ctx, int T, double variance_thresh);
+int edmp_sampler_read_schedule(edmp_ctx* ctx, double* beta, double* alpha, double* alpha_bar);
+/* replaces p_sample_using_posterior (diffusion.py:116-135) with the noise draw z made explicit.
+ * X (B,C,N) f64 updated in place.  zero_row0: apply quirk Q3 (row 0 of z zeroed when t == 1). */
+int edmp_psample_dev(edmp_ctx* ctx, double* X_dev, const float* eps_dev, const double* z_dev, int B, int C, int N,
+                     int t, int zero_row0);
+/* One reverse step of denoise_guided (diffusion.py:314-349) split at the only cross-row coupling:
+ *   step_a: eps = UNet(f32(X), t); X <- posterior(X, eps, z); if guided(t): g = raw gradient(clip(X[:, :, 1:-1])),
+ *           partial sum(g^2) -> device scalar.
+ *   step_b: if guided(t): X[:, :, 1:-1] -= sched[:, t-1] * mix(g, ||g||); X[:, :, 0] = start; X[:, :, -1] = goal.
+ * Between the two a multi-GPU caller may all-reduce edmp_sumsq_ptr_dev() (one f64).  Optional outputs (NULL to
+ * skip): eps_out_dev (B,C,N) f32, xpost_out_dev (B,C,N) f64, grad_out_dev (B,C,N-2) f64 (mixed gradient). */
+int edmp_step_a_dev(edmp_ctx* ctx, double* X_dev, const double* z_dev, int B, int t, const double* start,
+                    const double* goal, int zero_row0, float* eps_out_dev, double* xpost_out_dev);
+int edmp_step_b_dev(edmp_ctx* ctx, double* X_dev, int B, int t, const double* start, const double* goal,
+                    double* grad_out_dev);
+double* edmp_sumsq_ptr_dev(edmp_ctx* ctx);
+/* replaces Diffusion.denoise_guided (diffusion.py:300-356): noise (T+1,B,C,N) f64 on device, noise[0] = initial
+ * draw, noise[1 + T - t] = draw of step t.  X_out (B,C,N) f64.  guided = 0 runs the unguided loop
+ * (Diffusion.denoise, diffusion.py:253-278, batched).  t_stop: run steps T..t_stop+1 (0 = all).
+ * zero_row0: this shard holds global row 0 (quirk Q3). */
+int edmp_denoise_guided_dev(edmp_ctx* ctx, const double* noise_dev, int B, const double* start, const double* goal,
+                            int guided, int t_stop, int zero_row0, double* X_out_dev);
+
+/* ---- instrumentation ----------------------------------------------------------------------------------- */
+/* accumulate HIP-event time of the dominant kernel family (the MFMA conv kernels) while enabled */
+int edmp_prof_enable(edmp_ctx* ctx, int on);
+/* total ms and launch count of the MFMA conv kernels since the last reset (synchronises) */
+int edmp_prof_read(edmp_ctx* ctx, double* conv_ms, int64_t* conv_launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDMP_HIP_H */
