@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py — guided denoise-steps/sec of the EDMP sampler hot path on MI355X.
+
+One "step" = one full Diffusion.denoise_guided call (T=255 reverse steps, 125 of them guided) over one batch of
+B=1024 synthetic trajectories per GPU + the end-of-sampling best-trajectory selection (and, for N>1, the RCCL gather).
+value = trajectories x denoise-steps / second over all ranks.  Inputs (weights, scene tables, the (T+1,B,7,50) f64
+noise stream) are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+T, N, C = 255, 50, 7
+FULL_DIMS = (32, 64, 128, 256, 512, 512)
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+SURVEY_FLOPS_PER_TRAJ_STEP = 187_339_904
+
+
+def effective_cores() -> int:
+    """host cores this process may actually use: min(affinity, cgroup CPU quota).  os.cpu_count() alone over-counts
+    inside a quota-limited container and oversubscribed torch threads are orders of magnitude slower."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1024, help="rows per GPU")
+    ap.add_argument("--guides", type=str, default="1,2,3,4,5,10")
+    ap.add_argument("--obstacles", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=16, help="reverse steps of the bounded CPU-baseline sample")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from edmp_amd import dist as ED
+    from edmp_amd import guide_cfg as GC
+    from edmp_amd import scenes
+    from edmp_amd.diffusion import Diffusion
+    from edmp_amd.guide import IntersectionVolumeGuide
+    from edmp_amd.temporalunet import TemporalUNet
+
+    B = args.batch
+    guides = [int(g) for g in args.guides.split(",")]
+    cfgs = GC.build_guide_cfgs([GC.catalog_guide_dict(g) for g in guides], 0, T, rows_per_guide=GC.split_rows(B, len(guides)))
+    scene = scenes.random_scene(11 + rank, args.obstacles)  # every rank = its own planning problem replica
+    start, goal = scenes.DEFAULT_START, scenes.DEFAULT_GOAL
+
+    net = TemporalUNet(None, C, 32, dev, dims=FULL_DIMS, seed=1, max_batch=B)
+    guide = IntersectionVolumeGuide(scene, dev, cfgs, B)
+    dif = Diffusion(T, dev)
+    ctx = dif.ctx
+    noise_host = np.random.RandomState(1234 + rank).standard_normal((T + 1, B, C, N))
+    noise = ctx.to_dev(noise_host, torch.float64)
+    ctx.sync()
+
+    def one_call():
+        X = dif.denoise_guided(net, guide, N, C, cfgs["guidance_schedule"], batch_size=B, start=start, goal=goal, noise=noise, return_device=True)
+        vols, idx = guide.row_swept_volumes(start, goal, X)  # synchronises (argmin comes back to the host)
+        traj = X[idx].cpu().numpy()
+        ok = ED.geometric_success(float(vols[idx]), traj)
+        return ED.gather_best(float(vols[idx]), idx, traj, ok, device=dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        best = one_call()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        best = one_call()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    value = world * B * T * args.steps / dt
+
+    out = None
+    if rank == 0:
+        nominal, executed = net.flops_per_trajectory()
+        out = {
+            "metric": "guided denoise-steps/sec (trajectories x reverse steps)",
+            "value": value,
+            "unit": "traj-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"denoise_guided T={T} N={N} batch={B}/GPU, {len(guides)}-guide ensemble {guides}, {args.obstacles}-cuboid synthetic scene, full TemporalUNet (29.9M params, random init), f64 state / f32 denoiser+guide",
+                "global_batch": world * B,
+                "parallelism": f"row-sharded replicas x{world}, end-of-sampling RCCL gather" if world > 1 else "single GPU",
+            },
+            "best": {"rank": best["rank"], "row": best["index"], "swept_volume": best["volume"], "geometric_success_proxy": best["success"]},
+            "unet_flops_per_traj_step": {"nominal": nominal, "executed_after_tap_skipping": executed, "survey": SURVEY_FLOPS_PER_TRAJ_STEP},
+        }
+
+    # ---- roofline of the dominant kernel family (fp32-MFMA implicit-GEMM conv), N=1 only -------------------------
+    if world == 1 and rank == 0:
+        ctx.prof(True)
+        ctx.prof_read(reset=True)
+        one_call()
+        conv_ms, launches = ctx.prof_read(reset=True)
+        ctx.prof(False)
+        nominal, executed = net.flops_per_trajectory()
+        conv_nominal = nominal - 2.0 * N * C * FULL_DIMS[0]  # the 1x1 head is a separate VALU kernel
+        conv_exec = executed - 2.0 * N * C * FULL_DIMS[0]
+        ach = conv_nominal * B * T / (conv_ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "kernel": "edmp::conv_mfma_kernel<BM,BN,KC> (all Conv1d/ConvTranspose1d of the UNet)",
+            "bound": "mfma",
+            "achieved": ach,
+            "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": ach / PEAK_F32_MFMA_TFLOPS,
+            "traffic": None,
+            "achieved_executed": conv_exec * B * T / (conv_ms * 1e-3) / 1e12,
+            "launches": launches,
+            "avg_launch_us": 1e3 * conv_ms / max(launches, 1),
+            "flops_per_launch_nominal": conv_nominal * B * T / max(launches, 1),
+            "conv_ms_per_call": conv_ms,
+            "note": "achieved = nominal (every tap counted, SURVEY 8d) conv FLOPs / summed HIP-event time of the conv launches of one denoise_guided call; achieved_executed counts only taps not in the zero padding",
+        }
+
+    # ---- CPU baseline: the oracle (port of the reference) on this box's host cores, bounded sample -----------------
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        from edmp_amd import weights as W
+        from oracle import edmp_oracle as O
+
+        cores = effective_cores()
+        torch.set_num_threads(cores)
+        sd = W.init_state_dict(1, C, 32, FULL_DIMS)
+        om, og = O.UNetOracle(sd), O.GuideOracle(scene, cfgs, B)
+        k = args.cpu_steps
+        small = noise_host[: k + 1]
+        t0 = time.perf_counter()
+        O.denoise_guided(om, og, T, N, C, cfgs["guidance_schedule"], B, start, goal, noise=small, t_stop=T - k)  # the oracle reads noise[0..k] only
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": B * k / cdt,
+            "unit": "traj-steps/s",
+            "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"oracle (NumPy f64 + torch-CPU f32 restatement of the reference, no_grad) on the same workload, reverse steps t={T}..{T - k + 1} ({k} of {T} steps, {k // 2} guided), {cdt:.1f} s",
+        }
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

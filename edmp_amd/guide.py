@@ -161,7 +161,10 @@ class IntersectionVolumeGuide:
         """(B,) f32 t=0 swept volume per row and the argmin (first on ties)."""
         self._bind()
         ctx = self.ctx
-        X = ctx.to_dev(np.asarray(trajectories, dtype=np.float64), torch.float64)
+        if isinstance(trajectories, torch.Tensor) and trajectories.is_cuda:
+            X = trajectories.to(torch.float64).contiguous()
+        else:
+            X = ctx.to_dev(np.asarray(trajectories, dtype=np.float64), torch.float64)
         B, N = X.shape[0], X.shape[2]
         s = np.ascontiguousarray(np.asarray(start, dtype=np.float64).reshape(7))
         g = np.ascontiguousarray(np.asarray(goal, dtype=np.float64).reshape(7))
