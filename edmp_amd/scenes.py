@@ -39,3 +39,24 @@ def random_start_goal(seed: int):
 def cylinder_as_box(center, quat_xyzw, radius, height) -> np.ndarray:
     """one obstacle_config row for a cylinder, the way the reference feeds it to the guide (quirk Q9)."""
     return np.concatenate([np.asarray(center, float), np.asarray(quat_xyzw, float), [radius, radius, height]])
+
+
+class SyntheticDataset:
+    """Stand-in for ``TestDataset`` (datasets/load_test_dataset.py:15-189) with the same ``fetch_data`` output
+    contract: (obstacle_config, cuboid_config, cylinder_config, num_cuboids, num_cylinders, start_joints,
+    all_ik_goals).  scene_type 'tabletop' = yaw-only cuboids, anything else = free orientations.  IK goals are seeded
+    in-limit configurations (robofin/ikfast are not available)."""
+
+    def __init__(self, dataset_type="synthetic", d_path=None, scene_types=("stress",), num_scenes_per_type=1, n_obstacles=8, n_ik=100):
+        self.dataset_type = dataset_type
+        self.n_obstacles, self.n_ik = int(n_obstacles), int(n_ik)
+        n = 1 if num_scenes_per_type is None or num_scenes_per_type < 0 else int(num_scenes_per_type)
+        self.data_nums = {st: n for st in scene_types}
+
+    def fetch_data(self, scene_num, scene_type="stress"):
+        seed = 1000 * (sum(map(ord, scene_type)) % 97) + int(scene_num)
+        oc = random_scene(seed, self.n_obstacles, yaw_only=(scene_type == "tabletop"))
+        start, _ = random_start_goal(seed)
+        lo, hi = joint_limits()
+        iks = np.random.RandomState(seed + 2).uniform(lo, hi, (self.n_ik, 7))
+        return oc, oc.copy(), np.zeros((0, 10)), oc.shape[0], 0, start, iks

@@ -1,0 +1,81 @@
+#!/usr/bin/env python
+"""infer_serial.py — the reference's driver surface (infer_serial.py:14-170) on the MI355X-native sampler.
+
+    python infer_serial.py -c configs/cfg_c1_plumbing.yaml
+
+Same flow: run config (YAML, schema of benchmark/cfgs/cfg1.yaml) -> guide plugins (guides/cfgs/guide<N>.yaml schema)
+-> per-row guide_cfgs -> per scene: guide object, IK-goal filter (guide.cost at t=0, trust region 0.0008, nearest to
+start), Diffusion.denoise_guided, choose_best_trajectory.  Differences forced by missing third-party assets, all
+stated in DESIGN.md: scenes/IK goals are synthetic unless a dataset object is supplied, weights are random-init
+unless <model_dir>/TemporalUNetModel<T>_N<traj_len>/weights_latest.pt exists, success is the geometric proxy
+(pybullet absent)."""
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+from edmp_amd import dist as ED
+from edmp_amd import guide_cfg as GC
+from edmp_amd.diffusion import Diffusion
+from edmp_amd.guide import IntersectionVolumeGuide
+from edmp_amd.scenes import SyntheticDataset
+from edmp_amd.temporalunet import TemporalUNet
+
+
+def run(cfg_path, dataset=None, max_scenes=None, verbose=True):
+    benchmark_cfg = GC.load_yaml(cfg_path)
+    guides = benchmark_cfg["guide"]["guides"]
+    device = benchmark_cfg["model"]["device"]
+    traj_len = benchmark_cfg["model"]["traj_len"]
+    T = benchmark_cfg["model"]["T"]
+    num_channels = benchmark_cfg["model"]["num_channels"]
+    if dataset is None:
+        dataset = SyntheticDataset(benchmark_cfg["dataset"]["dataset_type"], d_path=benchmark_cfg["dataset"]["path"],
+                                   scene_types=benchmark_cfg["dataset"]["scene_types"],
+                                   num_scenes_per_type=benchmark_cfg["dataset"].get("num_scenes_per_type", 1))
+    guide_cfgs = GC.guide_cfgs_from_run_cfg(benchmark_cfg, base_dir=os.path.dirname(os.path.abspath(cfg_path)) + "/..")
+    total_batch_size = guide_cfgs["total_batch_size"]
+    diffuser = Diffusion(T=T, device=device)
+    model_name = benchmark_cfg["model"]["model_dir"] + "TemporalUNetModel" + str(T) + "_N" + str(traj_len)
+    if not os.path.exists(model_name):
+        if verbose:
+            print(f"[infer_serial] {model_name} not found: using a seeded random-init denoiser (no trained weights offline)")
+        model_name = None
+    denoiser = TemporalUNet(model_name=model_name, input_dim=num_channels, time_dim=32, dims=(32, 64, 128, 256, 512, 512), device=device,
+                            max_batch=total_batch_size)
+    t_success, i, results = 0, 0, []
+    for scene_type in benchmark_cfg["dataset"]["scene_types"]:
+        for scene_num in range(dataset.data_nums[scene_type]):
+            if max_scenes is not None and i >= max_scenes:
+                break
+            obstacle_config, _, _, _, _, start_joints, all_ik_goals = dataset.fetch_data(scene_num=scene_num, scene_type=scene_type)
+            t0 = time.time()
+            guide = IntersectionVolumeGuide(obstacle_config=obstacle_config, device=device, guide_cfgs=guide_cfgs, batch_size=total_batch_size)
+            # IK-goal filter                                                              infer_serial.py:117-129
+            volumes = guide.cost(torch.tensor(all_ik_goals.reshape((-1, 7, 1))), 0, batch_size=all_ik_goals.shape[0]).sum(axis=(1, 2)).cpu().numpy()
+            indices = np.argsort(volumes)
+            goal_joints = all_ik_goals[indices][volumes[indices] < np.min(volumes) + 0.0008]
+            goal_joints = goal_joints[np.argmin(np.linalg.norm(start_joints - goal_joints, axis=1))]
+            trajectories = diffuser.denoise_guided(model=denoiser, guide=guide, batch_size=total_batch_size, traj_len=traj_len,
+                                                   num_channels=num_channels, condition=True, benchmarking=True, start=start_joints,
+                                                   goal=goal_joints, guidance_schedule=guide_cfgs["guidance_schedule"])
+            vols, idx = guide.row_swept_volumes(start_joints, goal_joints, trajectories)
+            trajectory = trajectories[idx]
+            success = int(ED.geometric_success(float(vols[idx]), trajectory))
+            t_success += success
+            i += 1
+            results.append(dict(scene_type=scene_type, scene_num=scene_num, best_row=int(idx), swept_volume=float(vols[idx]), success_proxy=success,
+                                planning_time_s=time.time() - t0, trajectory=trajectory))
+            if verbose:
+                print(f"Scene {i} ({scene_type}/{scene_num}): planning {time.time() - t0:.2f} s, best row {idx}, swept volume {vols[idx]:.4g}, "
+                      f"geometric success (proxy) {success}   running {t_success}/{i}")
+    return results
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser(prog="Benchmarking Diffusion", description="Benchmarking with IK on Test sets")
+    parser.add_argument("-c", "--cfg_path", type=str, default="./configs/cfg_c1_plumbing.yaml")
+    args = parser.parse_args()
+    run(args.cfg_path)

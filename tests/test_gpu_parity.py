@@ -302,3 +302,14 @@ def test_full_size_properties():
     e_all = net(x, torch.tensor([200.0])).cpu().numpy()
     e_sub = net(x[300:400], torch.tensor([200.0])).cpu().numpy()
     assert np.array_equal(e_all[300:400], e_sub)
+
+
+def test_infer_serial_driver_c1():
+    """BASELINE configs[0] plumbing: guides [1], 4 rows, one scene, through the reference-shaped driver."""
+    import os
+
+    import infer_serial
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = infer_serial.run(os.path.join(root, "configs", "cfg_c1_plumbing.yaml"), verbose=False)
+    assert len(res) == 1 and res[0]["trajectory"].shape == (7, 50) and np.isfinite(res[0]["trajectory"]).all()

@@ -1,0 +1,181 @@
+"""CPU: host-side logic of the product package and the C-ABI surface (no compute calls without a GPU)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import yaml
+
+from tests.util import T, cfgs_for
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_build_guide_cfgs_matches_reference_arrays(golden):
+    from edmp_amd import guide_cfg as GC
+
+    g = golden("g1_guide_cfgs")
+    hyper = json.loads(str(g["hyper_json"]))
+    # (a) from the reference's own parsed YAML content
+    dicts = [{"hyperparameters": hyper[str(int(n))]} for n in g["guides"]]
+    c = GC.build_guide_cfgs(dicts, int(g["bpg"]), T)
+    # (b) from the built-in catalogue
+    c2 = cfgs_for(g["guides"], g["bpg"])
+    for k in ("clearance", "expansion", "guidance_method", "grad_norm", "guidance_schedule", "volume_trust_region"):
+        assert np.array_equal(c[k], g[k]), k
+        assert np.array_equal(c2[k], g[k]), k
+    assert c["total_batch_size"] == len(g["guides"]) * int(g["bpg"])
+    # guide18: isr3 [0,20) overwrites the tail of isr2 [10,40)
+    i18 = list(g["guides"]).index(18) * int(g["bpg"])
+    assert np.all(c["expansion"][i18, 10:20] == 0) and c["expansion"][i18, 20] > 0
+
+
+def test_yaml_plugin_round_trip(tmp_path):
+    from edmp_amd import guide_cfg as GC
+
+    GC.write_guide_yamls(str(tmp_path))
+    for n in GC.GUIDE_CATALOG:
+        d = GC.load_guide_dict(n, str(tmp_path))
+        assert d["hyperparameters"] == GC.catalog_guide_dict(n)["hyperparameters"]
+    # a user-supplied guide file overrides the catalogue
+    custom = GC.catalog_guide_dict(1)
+    custom["hyperparameters"]["obstacle_clearance"]["range"] = [0.2, 0.3]
+    with open(tmp_path / "cfgs" / "guide1.yaml", "w") as f:
+        yaml.safe_dump(custom, f)
+    run_cfg = {"guide": {"guides": [1, 10], "batch_size_per_guide": 3, "guide_path": str(tmp_path)}, "model": {"T": T}}
+    c = GC.guide_cfgs_from_run_cfg(run_cfg)
+    assert c["total_batch_size"] == 6 and c["clearance"][0, 0] == 0.2 and c["clearance"][0, -1] == 0.3
+    assert c["guidance_method"].tolist() == [0, 0, 0, 1, 1, 1]
+    with pytest.raises(FileNotFoundError):
+        GC.load_guide_dict(6, str(tmp_path))  # guide6.yaml does not exist in the reference either
+
+
+def test_split_rows_and_ragged_guides():
+    from edmp_amd import guide_cfg as GC
+
+    r = GC.split_rows(1024, 6)
+    assert sum(r) == 1024 and max(r) - min(r) <= 1
+    c = cfgs_for([1, 2, 3, 4, 5, 10], 0, rows_per_guide=r)
+    assert c["total_batch_size"] == 1024 and int(c["guidance_method"].sum()) == r[-1]
+
+
+def test_noise_stream_equals_reference_draw_order():
+    """np.random.multivariate_normal(0, I_50, size=(B,7)) (diffusion.py:303,126) == standard_normal((B,7,50))."""
+    from edmp_amd.diffusion import draw_noise
+
+    B = 3
+    np.random.seed(42)
+    ref = [np.random.multivariate_normal(mean=np.zeros(50), cov=np.eye(50), size=(B, 7)) for _ in range(4)]
+    np.random.seed(42)
+    mine = draw_noise(3, B, 7, 50)
+    assert mine.shape == (4, B, 7, 50)
+    for i in range(4):
+        assert np.array_equal(mine[i], ref[i])
+
+
+def test_weights_inventory():
+    from edmp_amd import weights as W
+
+    s = W.unet_param_shapes()
+    assert len(s) == 290 and sum(int(np.prod(v)) for v in s.values()) == 29_938_471
+    sd = W.init_state_dict(3)
+    assert W.infer_dims(sd) == (7, 32, (32, 64, 128, 256, 512, 512))
+    assert sd["up_samplers.0.up.3.weight"].shape == (512, 512, 4)
+    assert "down_samplers.5.down.3.weight" not in sd and "down_samplers.1.down.1.residual_conv.weight" not in sd
+    sd2 = W.init_state_dict(3)
+    assert all(np.array_equal(sd[k], sd2[k]) for k in sd)
+
+
+def test_checkpoint_format_round_trip(tmp_path):
+    from edmp_amd import weights as W
+
+    dims = (16, 16, 32, 32, 64, 64)
+    sd = W.init_state_dict(1, dims=dims)
+    W.save_checkpoint_dir(str(tmp_path / "m"), sd)
+    assert os.path.exists(tmp_path / "m" / "weights_latest.pt") and os.path.exists(tmp_path / "m" / "losses.npy")
+    back = W.load_checkpoint_dir(str(tmp_path / "m"))
+    assert list(back) == list(sd) and all(np.array_equal(back[k], sd[k]) for k in sd)
+
+
+def test_franka_tables():
+    from edmp_amd import franka
+    from oracle import edmp_oracle as O
+
+    assert np.allclose(franka.static_frames(), np.array(O.STATIC_FRAMES, dtype=np.float32)[:, :3, :])
+    dh = franka.dh_table()
+    assert dh.shape == (7, 4) and dh[1, 2] != 0 and abs(dh[1, 2]) < 1e-7 and dh[1, 3] == -1.0  # f32 cos(pi/2) quirk
+    he = franka.link_half_extents()
+    assert np.allclose(he * 2, O.link_dimensions_effective(O.PLACEHOLDER_LINK_EXTENTS).numpy())
+    lo, hi = franka.joint_limits()
+    olo, ohi = O.joint_limits()
+    assert np.array_equal(lo, olo) and np.array_equal(hi, ohi)
+    with pytest.raises(ValueError):
+        franka.link_half_extents(np.zeros((8, 3)))
+
+
+def test_row_classes():
+    from edmp_amd.guide import row_classes
+
+    c = cfgs_for([1, 10, 1, 18], 3)
+    rc, cc, ce = row_classes(c["clearance"], c["expansion"])
+    assert rc.tolist() == [0, 0, 0, 1, 1, 1, 0, 0, 0, 2, 2, 2] and cc.shape == (3, T) and ce.shape == (3, T)
+
+
+def test_scene_contract():
+    from edmp_amd import scenes
+
+    s = scenes.random_scene(1, 8)
+    assert s.shape == (8, 10) and np.allclose(np.linalg.norm(s[:, 3:7], axis=1), 1)
+    assert np.array_equal(s, scenes.random_scene(1, 8))
+    row = scenes.cylinder_as_box([0.5, 0, 0.2], [0, 0, 0, 1], 0.1, 0.4)
+    assert row[7:].tolist() == [0.1, 0.1, 0.4]  # Q9: radius, not diameter
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from edmp_amd import _capi
+
+    hdr = open(os.path.join(ROOT, "include", "edmp_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(edmp_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
+    lib = _capi.load()  # dlopen works without a GPU
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.edmp_version() >= 100
+    # struct layout the header promises
+    assert ctypes.sizeof(_capi.UNetDesc) == 4 * (3 + 8 + 2)
+    d = _capi.UNetDesc()
+    d.input_dim, d.time_dim, d.n_levels, d.horizon, d.T = 7, 32, 6, 50, 255
+    for i, v in enumerate((32, 64, 128, 256, 512, 512)):
+        d.dims[i] = v
+    assert lib.edmp_unet_param_count(ctypes.byref(d)) == 29_938_471  # host-only entry point
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+
+    from edmp_amd import _capi
+    from edmp_amd.runtime import get_context
+
+    with pytest.raises(_capi.EdmpError):
+        get_context("cpu")
+    if not torch.cuda.is_available():
+        with pytest.raises(_capi.EdmpError):
+            get_context("cuda:0")
+        from edmp_amd.diffusion import Diffusion
+
+        with pytest.raises(_capi.EdmpError):
+            Diffusion(255, "cuda:0")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "edmp_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+    drv = open(os.path.join(ROOT, "infer_serial.py")).read() if os.path.exists(os.path.join(ROOT, "infer_serial.py")) else ""
+    assert not re.search(r"^\s*(from|import)\s+oracle", drv, flags=re.M)

@@ -1,0 +1,142 @@
+"""CPU: the oracle (oracle/edmp_oracle.py) against the golden vectors captured from the unmodified reference.
+The oracle was asserted bit-exact against the reference when the fixtures were generated (oracle/gen_golden.py);
+these tests keep it pinned wherever the suite runs (torch/NumPy builds may differ in the last ulp, hence the tiny
+tolerances instead of array_equal for the float32 paths)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import edmp_oracle as O
+from tests.util import FULL_DIMS, T, TINY_DIMS, cfgs_for, maxabs, noise_for, rmse
+
+
+def test_g1_guide_cfgs(golden):
+    g = golden("g1_guide_cfgs")
+    hyper = json.loads(str(g["hyper_json"]))
+    dicts = [{"hyperparameters": hyper[str(int(n))]} for n in g["guides"]]
+    c = O.build_guide_cfgs(dicts, int(g["bpg"]), T)
+    for k in ("clearance", "expansion", "guidance_method", "grad_norm", "guidance_schedule", "volume_trust_region"):
+        assert np.array_equal(c[k], g[k]), k
+
+
+def test_g2_schedule(golden):
+    g = golden("g2_schedule")
+    b, a, ab = O.schedule(T)
+    assert np.array_equal(b, g["beta"]) and np.array_equal(a, g["alpha"]) and np.array_equal(ab, g["alpha_bar"])
+    assert abs(b[0] - 7.843e-05) < 1e-8 and b[-1] == 0.02 and abs(ab[-1] - 0.075981) < 1e-6
+
+
+def test_g3_obstacles(golden):
+    g = golden("g3_obstacles")
+    cfgs = cfgs_for(g["guides"], g["bpg"])
+    og = O.GuideOracle(g["scene"], cfgs, cfgs["total_batch_size"])
+    for i, t in enumerate(g["ts"]):
+        mn, mx = og.obstacles(int(t))
+        assert maxabs(mn.numpy(), g["obs_min"][i]) <= 1e-7 and maxabs(mx.numpy(), g["obs_max"][i]) <= 1e-7
+
+
+def test_quat_matches_scipy():
+    from scipy.spatial.transform import Rotation as R
+
+    rs = np.random.RandomState(0)
+    for _ in range(20):
+        q = rs.standard_normal(4)
+        assert maxabs(O.quat_xyzw_to_matrix(q), R.from_quat(q).as_matrix()) <= 1e-15
+
+
+def test_g4_fk(golden):
+    g = golden("g4_fk")
+    q = torch.tensor(g["joints"])
+    assert maxabs(O.forward_kinematics(q).numpy(), g["fk"]) <= 1e-6
+    assert maxabs(O.get_link_transform(q).numpy(), g["link_T"]) <= 1e-6
+    lv = O.box_vertices(O.link_dimensions_effective(O.PLACEHOLDER_LINK_EXTENTS)).numpy()
+    assert np.array_equal(lv, g["link_vertices"])  # corner order + finger y x4
+
+
+def test_g5_costs(golden):
+    g = golden("g5_costs")
+    cfgs = cfgs_for(g["guides"], g["bpg"])
+    og = O.GuideOracle(g["scene"], cfgs, cfgs["total_batch_size"])
+    for t in (0, 128):
+        assert maxabs(og.cost(g["joints"], t).numpy(), g[f"iv_t{t}"]) <= 1e-7
+        assert maxabs(og.swept_volume_cost(g["joints"], g["start"], g["goal"], t).numpy(), g[f"sv_t{t}"]) <= 1e-7
+
+
+def test_g6_gradient(golden):
+    g = golden("g6_gradient")
+    cfgs = cfgs_for(g["guides"], g["bpg"])
+    B = cfgs["total_batch_size"]
+    og = O.GuideOracle(g["scene"], cfgs, B)
+    assert maxabs(og.get_gradient(g["joints"], g["start"], g["goal"], 128), g["grad_t128"]) <= 1e-5
+    assert maxabs(og.get_gradient(g["joints_ties"], g["start"], g["goal"], 128), g["grad_ties_t128"]) <= 1e-5
+    assert np.isnan(O.GuideOracle(g["scene_far"], cfgs, B).get_gradient(g["joints"], g["start"], g["goal"], 128)).all()  # Q7
+
+
+def test_g7_psample(golden):
+    g = golden("g7_psample")
+    b, a, ab = O.schedule(T)
+    for t in (255, 128, 2, 1):
+        np.random.seed(int(g["seed_base"]) + t)
+        z = np.random.standard_normal(g["x"].shape)
+        out = O.p_sample_using_posterior(g["x"], t, g["eps"], z, b, a, ab)
+        assert np.array_equal(out, g[f"x_out_t{t}"]), t
+    # Q1: noise scale is beta_t (not sqrt(beta_t)); Q3: only row 0 loses its noise at t == 1
+    z = np.ones_like(g["x"])
+    d = O.p_sample_using_posterior(g["x"], 1, g["eps"], z, b, a, ab) - O.p_sample_using_posterior(g["x"], 1, g["eps"], 0 * z, b, a, ab)
+    assert np.all(d[0] == 0) and np.allclose(d[1:], b[0])
+
+
+@pytest.mark.parametrize("tag,dims", [("tiny", TINY_DIMS), ("full", FULL_DIMS)])
+def test_g8_unet(golden, tag, dims):
+    from edmp_amd import weights as W
+
+    g = golden(f"g8_unet_{tag}")
+    sd = W.init_state_dict(int(g["seed"]), 7, 32, dims)
+    net = O.UNetOracle(sd)
+    x = torch.from_numpy(g["x"])
+    for tt in (255, 1):
+        assert maxabs(net(x, torch.tensor([float(tt)])).numpy(), g[f"eps_t{tt}"]) <= 2e-5, tt
+
+
+@pytest.mark.parametrize("tag", ["c1_g1_b4", "mixed_b12"])
+def test_g9_teacher_forced(golden, tag):
+    from edmp_amd import weights as W
+
+    g = golden(f"g9_trace_{tag}")
+    cfgs = cfgs_for(g["guides"], g["bpg"])
+    B = cfgs["total_batch_size"]
+    net = O.UNetOracle(W.init_state_dict(5, 7, 32, TINY_DIMS))
+    og = O.GuideOracle(g["scene"], cfgs, B)
+    noise = noise_for(g["seed"], B)
+    b, a, ab = O.schedule(T)
+    for t in (255, 254, 128, 6, 1):
+        x = g[f"x_in_{t}"]
+        eps = net(torch.tensor(x, dtype=torch.float32), torch.tensor([float(t)])).numpy()
+        assert rmse(eps, g[f"eps_{t}"]) <= 1e-5
+        xp = O.p_sample_using_posterior(x, t, g[f"eps_{t}"], noise[1 + (T - t)], b, a, ab)
+        assert maxabs(xp, g[f"x_post_{t}"]) <= 1e-12
+        if f"grad_{t}" in g.files:
+            gr = og.get_gradient(O.clip_joints(xp[:, :, 1:-1]), g["start"], g["goal"], t)
+            assert rmse(gr, g[f"grad_{t}"]) <= 1e-6
+    # Q8: guided steps are the even t >= 6
+    guided = [int(t) for t in g["steps"] if f"grad_{int(t)}" in g.files]
+    assert guided == [int(t) for t in g["steps"] if int(t) % 2 == 0 and int(t) >= 5]
+
+
+def test_g10_best(golden):
+    g = golden("g9_trace_c3_g6_b12")
+    cfgs = cfgs_for(g["guides"], g["bpg"])
+    og = O.GuideOracle(g["scene"], cfgs, cfgs["total_batch_size"])
+    v = og.row_swept_volumes(g["start"], g["goal"], g["X_final"]).numpy()
+    assert np.allclose(v, g["row_volumes"], rtol=1e-5, atol=1e-7)
+    assert np.array_equal(og.choose_best_trajectory(g["start"], g["goal"], g["X_final"]), g["best"])
+
+
+def test_g11_ik(golden):
+    g = golden("g11_ik_filter")
+    cfgs = cfgs_for([1, 10, 11, 18, 9, 13], 2)
+    og = O.GuideOracle(g["scene"], cfgs, 12)
+    v = og.cost(g["ik"].reshape((-1, 7, 1)), 0, batch_size=g["ik"].shape[0]).sum(axis=(1, 2)).numpy()
+    assert maxabs(v, g["volumes"]) <= 1e-7
