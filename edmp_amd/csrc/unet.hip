@@ -176,17 +176,22 @@ __global__ void pack_input_kernel(const float* __restrict__ x, float* __restrict
 // Implicit-GEMM Conv1d / ConvTranspose1d on the fp32 MFMA.  Block = 256 threads = 4 waves, tile BM samples x BN
 // output channels at ONE output position; K runs over (valid tap, source, channel chunk of KC).
 // LDS tiles are [rows][KC + 4] so that the ds_read_b128 of a 16-lane group hits 16 distinct 4-bank slots.
+// The valid taps of one output position form an arithmetic sequence (tap = k0 + i*dk, input position = l0 + i*dl), so
+// the whole K walk is scalar arithmetic; global loads are unconditional (row indices clamped, results masked at the
+// store) so that the loop body is straight-line: 4 global_load_dwordx4, 8 ds_read_b128, 16 MFMA, 4 ds_write_b128.
 template <int BM, int BN, int KC>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
     constexpr int LDK = KC + 4;
     constexpr int WN = BN / 32;
-    constexpr int F4_PER_ROW = KC / 4;
-    constexpr int A_F4 = BM * F4_PER_ROW;
-    constexpr int B_F4 = BN * F4_PER_ROW;
+    constexpr int F4R = KC / 4;
+    constexpr int A_F4 = BM * F4R;
+    constexpr int B_F4 = BN * F4R;
     constexpr int A_IT = (A_F4 + 255) / 256;
     constexpr int B_IT = (B_F4 + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDK];
+    constexpr bool A_FULL = (A_F4 % 256) == 0;
+    constexpr bool B_FULL = (B_F4 % 256) == 0;
     constexpr int STAGE = (BM + BN) * LDK;  // floats per pipeline stage: A tile then B tile
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -198,117 +203,136 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
     const int b0 = blockIdx.x * BM;
     const int Cin = p.C1 + p.C2;
 
-    // valid taps for this output position (block-uniform), kept in LDS so that no runtime-indexed register array
-    // (= scratch memory) is created
-    __shared__ int s_tap[8], s_li[8], s_nvt;
-    if (tid == 0) {
-        int n = 0;
-        for (int k = 0; k < p.ntaps; ++k) {
-            int li;
-            bool ok;
-            if (!p.transposed) {
-                li = lo * p.stride + k - p.pad;
-                ok = (li >= 0) && (li < p.Lin);
-            } else {
-                int num = lo + p.pad - k;
-                li = num / p.stride;
-                ok = (num >= 0) && (num % p.stride == 0) && (li < p.Lin);
-            }
-            if (ok) {
-                s_tap[n] = k;
-                s_li[n] = li;
-                ++n;
-            }
-        }
-        s_nvt = n;
+    int k0, dk, l0, dl, nvt;
+    if (!p.transposed) {  // li = lo*stride + k - pad must lie in [0, Lin)
+        const int base = lo * p.stride - p.pad;
+        const int kmin = max(0, -base);
+        const int kmax = min(p.ntaps - 1, p.Lin - 1 - base);
+        k0 = kmin;
+        dk = 1;
+        l0 = base + kmin;
+        dl = 1;
+        nvt = max(0, kmax - kmin + 1);
+    } else {  // li*stride + k - pad = lo  ->  k = r + i*stride, li = (lo + pad - r)/stride - i
+        const int r = (lo + p.pad) % p.stride;
+        const int li_first = (lo + p.pad - r) / p.stride;
+        const int i_lo = max(0, li_first - (p.Lin - 1));
+        const int i_hi = (p.ntaps - 1 - r) >= 0 ? min(li_first, (p.ntaps - 1 - r) / p.stride) : -1;
+        k0 = r + i_lo * p.stride;
+        dk = p.stride;
+        l0 = li_first - i_lo;
+        dl = -1;
+        nvt = max(0, i_hi - i_lo + 1);
     }
-    __syncthreads();
-    const int nvt = s_nvt;
     const int ch1 = p.C1 / KC, ch2 = p.C2 / KC;
-    const int chunks_per_tap = ch1 + ch2;
-    const int nK = nvt * chunks_per_tap;
+    const int cpt = ch1 + ch2;  // chunks per tap
+    const int nK = nvt * cpt;
 
-    float4 ra[A_IT], rb[B_IT];
+    // per-thread, chunk-invariant parts of the global addresses (element offsets).  Scalars, not arrays: hipcc keeps
+    // small runtime-looking arrays in scratch memory once scheduling barriers are present.
+#define EDMP_DECL_A(i)                                                     \
+    const int fa##i = tid + i * 256;                                       \
+    const int ba##i = min(b0 + fa##i / F4R, p.B - 1);                      \
+    const int a1_##i = ba##i * p.Lin * p.C1 + (fa##i % F4R) * 4;           \
+    const int a2_##i = ba##i * p.Lin * p.C2 + (fa##i % F4R) * 4;           \
+    const int al_##i = (fa##i / F4R) * LDK + (fa##i % F4R) * 4;            \
+    const bool ap_##i = (i < A_IT) && (A_FULL || fa##i < A_F4);            \
+    float4 ra##i = make_float4(0.f, 0.f, 0.f, 0.f);
+#define EDMP_DECL_B(i)                                                     \
+    const int fb##i = tid + i * 256;                                       \
+    const int w_##i = min(n0 + fb##i / F4R, p.Cout - 1) * Cin + (fb##i % F4R) * 4; \
+    const int bl_##i = BM * LDK + (fb##i / F4R) * LDK + (fb##i % F4R) * 4; \
+    const bool bp_##i = (i < B_IT) && (B_FULL || fb##i < B_F4);            \
+    float4 rb##i = make_float4(0.f, 0.f, 0.f, 0.f);
+    EDMP_DECL_A(0) EDMP_DECL_A(1) EDMP_DECL_A(2) EDMP_DECL_A(3)
+    EDMP_DECL_B(0) EDMP_DECL_B(1) EDMP_DECL_B(2) EDMP_DECL_B(3)
+    static_assert(A_IT <= 4 && B_IT <= 4, "tile too large for the staging code");
+    int ld_ti = 0, ld_cc = 0;  // next chunk to fetch (block-uniform)
 
-    auto load_chunk = [&](int kk) {
-        int ti = kk / chunks_per_tap;
-        int cc = kk - ti * chunks_per_tap;
-        const int tap = s_tap[ti], li = s_li[ti];
-        const float* src;
-        int Cs, ci0, wofs;
-        if (cc < ch1) {
-            src = p.src1;
-            Cs = p.C1;
-            ci0 = cc * KC;
-            wofs = ci0;
-        } else {
-            src = p.src2;
-            Cs = p.C2;
-            ci0 = (cc - ch1) * KC;
-            wofs = p.C1 + ci0;
-        }
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            int f = tid + it * 256;
-            int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < A_F4 && (b0 + r) < p.B)
-                v = *reinterpret_cast<const float4*>(src + ((size_t)(b0 + r) * p.Lin + li) * Cs + ci0 + c4 * 4);
-            ra[it] = v;
-        }
-        const float* wt = p.W + (size_t)tap * p.Cout * Cin + wofs;
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            int f = tid + it * 256;
-            int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < B_F4 && (n0 + r) < p.Cout) v = *reinterpret_cast<const float4*>(wt + (size_t)(n0 + r) * Cin + c4 * 4);
-            rb[it] = v;
-        }
-    };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            int f = tid + it * 256;
-            int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
-            if (f < A_F4) *reinterpret_cast<float4*>(lds + buf * STAGE + r * LDK + c4 * 4) = ra[it];
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            int f = tid + it * 256;
-            int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
-            if (f < B_F4) *reinterpret_cast<float4*>(lds + buf * STAGE + BM * LDK + r * LDK + c4 * 4) = rb[it];
-        }
-    };
+#define EDMP_LDA(i) \
+    if (ap_##i) ra##i = *reinterpret_cast<const float4*>(abase_ + (first_ ? a1_##i : a2_##i));
+#define EDMP_LDB(i) \
+    if (bp_##i) rb##i = *reinterpret_cast<const float4*>(wbase_ + w_##i);
+// issue the global loads of chunk (ld_ti, ld_cc) and advance the chunk cursor
+#define EDMP_LOAD_NEXT()                                                                                      \
+    {                                                                                                         \
+        const int tap_ = k0 + ld_ti * dk;                                                                     \
+        const int li_ = l0 + ld_ti * dl;                                                                      \
+        const bool first_ = ld_cc < ch1;                                                                      \
+        const float* src_ = first_ ? p.src1 : p.src2;                                                         \
+        const int Cs_ = first_ ? p.C1 : p.C2;                                                                 \
+        const int ci0_ = (first_ ? ld_cc : ld_cc - ch1) * KC;                                                 \
+        const float* abase_ = src_ + (size_t)li_ * Cs_ + ci0_;                                                \
+        const float* wbase_ = p.W + (size_t)tap_ * p.Cout * Cin + (first_ ? 0 : p.C1) + ci0_;                 \
+        EDMP_LDA(0) EDMP_LDA(1) EDMP_LDA(2) EDMP_LDA(3) EDMP_LDB(0) EDMP_LDB(1) EDMP_LDB(2) EDMP_LDB(3)                              \
+        if (++ld_cc == cpt) {                                                                                 \
+            ld_cc = 0;                                                                                        \
+            ++ld_ti;                                                                                          \
+        }                                                                                                     \
+    }
+#define EDMP_STA(i) \
+    if (ap_##i) *reinterpret_cast<float4*>(st_ + al_##i) = ra##i;
+#define EDMP_STB(i) \
+    if (bp_##i) *reinterpret_cast<float4*>(st_ + bl_##i) = rb##i;
+#define EDMP_STORE_STAGE(buf)                                                     \
+    {                                                                             \
+        float* st_ = lds + (buf) * STAGE;                                         \
+        EDMP_STA(0) EDMP_STA(1) EDMP_STA(2) EDMP_STA(3) EDMP_STB(0) EDMP_STB(1) EDMP_STB(2) EDMP_STB(3) \
+    }
 
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 
-    if (nK > 0) {
-        load_chunk(0);
-        store_chunk(0);
-    }
-    __syncthreads();
     const int arow = (wm * 32 + (lane & 31)) * LDK + 4 * (lane >> 5);
-    const int brow = (wn * 32 + (lane & 31)) * LDK + 4 * (lane >> 5);
-    for (int kk = 0; kk < nK; ++kk) {
-        const int cur = kk & 1;
-        if (kk + 1 < nK) load_chunk(kk + 1);
-        const float* a_s = lds + cur * STAGE + arow;
-        const float* b_s = lds + cur * STAGE + BM * LDK + brow;
-#pragma unroll
-        for (int j = 0; j < KC / 8; ++j) {
-            float4 a4 = *reinterpret_cast<const float4*>(a_s + 8 * j);
-            float4 b4 = *reinterpret_cast<const float4*>(b_s + 8 * j);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
-        }
-        if (kk + 1 < nK) store_chunk(cur ^ 1);
+    const int brow = BM * LDK + (wn * 32 + (lane & 31)) * LDK + 4 * (lane >> 5);
+    if (nK > 0) {
+        EDMP_LOAD_NEXT();
+        EDMP_STORE_STAGE(0);
         __syncthreads();
+        // steady state: every iteration prefetches chunk kk+1 while the MFMAs consume chunk kk
+        for (int kk = 0; kk < nK - 1; ++kk) {
+            const int cur = kk & 1;
+            EDMP_LOAD_NEXT();
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (hipcc otherwise sinks it)
+            const float* a_s = lds + cur * STAGE + arow;
+            const float* b_s = lds + cur * STAGE + brow;
+#pragma unroll
+            for (int j = 0; j < KC / 8; ++j) {
+                const float4 a4 = *reinterpret_cast<const float4*>(a_s + 8 * j);
+                const float4 b4 = *reinterpret_cast<const float4*>(b_s + 8 * j);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            EDMP_STORE_STAGE(cur ^ 1);
+            __syncthreads();
+        }
+        {  // last chunk: nothing left to prefetch
+            const int cur = (nK - 1) & 1;
+            const float* a_s = lds + cur * STAGE + arow;
+            const float* b_s = lds + cur * STAGE + brow;
+#pragma unroll
+            for (int j = 0; j < KC / 8; ++j) {
+                const float4 a4 = *reinterpret_cast<const float4*>(a_s + 8 * j);
+                const float4 b4 = *reinterpret_cast<const float4*>(b_s + 8 * j);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+            }
+        }
     }
+#undef EDMP_LOAD_NEXT
+#undef EDMP_STORE_STAGE
+#undef EDMP_LDA
+#undef EDMP_LDB
+#undef EDMP_STA
+#undef EDMP_STB
+#undef EDMP_DECL_A
+#undef EDMP_DECL_B
 
     // epilogue: + bias, store [b][lo][co].  acc[r]: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
     const int co = n0 + wn * 32 + (lane & 31);
@@ -365,7 +389,7 @@ __global__ __launch_bounds__(256) void gn_mish_kernel(GnP p) {
             int ch = g * cg + c;
             float scale = rstd * p.gamma[ch];
             float shift = p.beta[ch] - scale * mean;
-            float y = mish_f(v[i] * scale + shift);
+            float y = mish_fast(v[i] * scale + shift);
             if (p.add_tbias) y += p.add_tbias[ch];
             if (p.add_res) y += p.add_res[((size_t)b * p.L + l) * p.C + ch];
             base[(size_t)l * p.C + c] = y;
@@ -445,17 +469,18 @@ static void launch_conv_t(const ConvP& p, hipStream_t s) {
 }
 static int pick_kc(const ConvP& p) {
     auto ok = [&](int kc) { return p.C1 % kc == 0 && (p.C2 == 0 || p.C2 % kc == 0); };
-    return ok(32) ? 32 : ok(16) ? 16 : 8;
+    return ok(64) ? 64 : ok(32) ? 32 : ok(16) ? 16 : 8;
 }
 static void launch_conv(const ConvP& p, hipStream_t s) {
     const int kc = pick_kc(p);
     const bool wide = (p.Cout % 64 == 0);
     if (wide) {
-        if (kc == 32) launch_conv_t<64, 64, 32>(p, s);
+        if (kc == 64) launch_conv_t<64, 64, 64>(p, s);
+        else if (kc == 32) launch_conv_t<64, 64, 32>(p, s);
         else if (kc == 16) launch_conv_t<64, 64, 16>(p, s);
         else launch_conv_t<64, 64, 8>(p, s);
     } else {
-        if (kc == 32) launch_conv_t<128, 32, 32>(p, s);
+        if (kc >= 32) launch_conv_t<128, 32, 32>(p, s);
         else if (kc == 16) launch_conv_t<128, 32, 16>(p, s);
         else launch_conv_t<128, 32, 8>(p, s);
     }
