@@ -129,11 +129,28 @@ struct GnP {
     int L, C, B;
 };
 
-enum OpKind { OP_CONV = 0, OP_GN = 1 };
+struct RcbP {
+    const float* src1;
+    const float* src2;
+    int C1, C2;
+    const float* W;  // [5][Cout][C1+C2]
+    const float* bias;
+    const float* gamma;
+    const float* beta;
+    const float* add_tb;   // [Cout] time bias of step t, or nullptr
+    const float* add_res;  // [B][L][Cout] residual, or nullptr
+    float* dst;            // [B][L][Cout]
+    int Cout;
+    int B;
+};
+
+enum OpKind { OP_CONV = 0, OP_GN = 1, OP_RCB = 2 };
 struct Op {
     OpKind kind;
     ConvP cv;
     GnP gn;
+    RcbP rc;
+    int rc_L;     // OP_RCB: positions
     int tb_off;   // GN: offset into the time-bias row, -1 if none
     double flops_nominal, flops_exec;  // CONV: per trajectory
 };
@@ -347,6 +364,241 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused Conv1dBlock of the wide levels: Conv1d(k=5, pad=2) + bias -> GroupNorm(8) -> Mish -> (+ time-bias | + residual)
+// (blocks.py:22-28 and the adds of blocks.py:162-164) in ONE launch, for Cout/8 in {32, 64} and L in {2, 4, 7}.
+//
+// A workgroup owns 32 samples x ONE GroupNorm group (CG channels) x ALL L output positions, so the normalisation
+// statistics are complete inside the workgroup and the raw convolution output never travels to HBM.
+// K step = 32 input channels of ALL L input positions (A: [L][32][36] floats) + the CG x 32 weight slab of every tap
+// that can be valid (B: [taps][CG][36]); a wave owns up to two 32x32 output tiles (position l, 32-channel slab) and,
+// per step, runs 16 MFMAs for every input position within +-2 of its l (taps in the zero padding do not exist).
+// That is 32..112 MFMAs per wave per barrier instead of 16, and 8x less activation re-reading than the per-position
+// tiling of conv_mfma_kernel.  grid = (8 groups, B/32): blockIdx.x = group, so one XCD's L2 holds one group's weights.
+
+template <int CG, int L>
+struct RcbCfg {
+    static constexpr int KC = 32, LDK = KC + 4;
+    static constexpr int S = CG / 32;
+    static constexpr int NTILE = L * S;
+    static constexpr int NT = (NTILE + 3) / 4;
+    static constexpr int KT0 = (L == 2) ? 1 : 0;
+    static constexpr int NTAP = (L == 2) ? 3 : 5;
+    static constexpr int A_FL = L * 32 * LDK;
+    static constexpr int B_FL = NTAP * CG * LDK;
+    static constexpr int STAGE = A_FL + B_FL;
+    static constexpr int NA = L;
+    static constexpr int NB = NTAP * CG / 32;
+    static constexpr int YS = L * CG + 4;
+    static constexpr int NF4 = L * CG / 32;  // float4 per thread in the epilogue
+    static constexpr size_t lds_bytes() {
+        size_t b = 2 * (size_t)STAGE * sizeof(float);
+        size_t y = 32 * (size_t)YS * sizeof(float);
+        size_t m = b > y ? b : y;
+        return m > 83968 ? m : 83968;  // > 80 KiB: at most one workgroup per CU, so 256 workgroups cover 256 CUs
+    }
+};
+
+template <int CG, int L>
+__global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
+    using Cf = RcbCfg<CG, L>;
+    constexpr int KC = Cf::KC, LDK = Cf::LDK, S = Cf::S, NTILE = Cf::NTILE, NT = Cf::NT, KT0 = Cf::KT0;
+    constexpr int A_FL = Cf::A_FL, STAGE = Cf::STAGE, NA = Cf::NA, NB = Cf::NB, YS = Cf::YS, NF4 = Cf::NF4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int co0 = blockIdx.x * CG;
+    const int b0 = blockIdx.y * 32;
+    const int Cin = p.C1 + p.C2;
+    const int ch1 = p.C1 / KC, ch2 = p.C2 / KC;
+    const int nK = ch1 + ch2;
+
+    // staging maps (chunk invariant)
+    const int srow = tid >> 3, sc4 = (tid & 7) * 4;
+    const int sb = min(b0 + srow, p.B - 1);
+    const int a_g1 = sb * L * p.C1 + sc4;  // + l'*C1 + ci0
+    const int a_g2 = sb * L * p.C2 + sc4;
+    const int a_l = srow * LDK + sc4;      // + l'*(32*LDK)
+    // staging registers are individual scalars: hipcc parks small arrays in scratch memory once scheduling
+    // barriers pin the prefetch (seen with ROCm 7.2), which would serialise every load behind a vmcnt(0)
+#define EDMP_REP7(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6)
+#define EDMP_REP10(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9)
+    static_assert(NA <= 7 && NB <= 10, "staging macros cover NA <= 7, NB <= 10");
+#define EDMP_DECL_RB(i)                                                                              \
+    const int wg##i = ((KT0 + (tid + i * 256) / (CG * 8)) * p.Cout + co0 + (((tid + i * 256) % (CG * 8)) >> 3)) * Cin + sc4; \
+    const int bl##i = A_FL + (((tid + i * 256) / (CG * 8)) * CG + (((tid + i * 256) % (CG * 8)) >> 3)) * LDK + sc4;          \
+    float4 rb##i = make_float4(0.f, 0.f, 0.f, 0.f);
+#define EDMP_DECL_RA(i) float4 ra##i = make_float4(0.f, 0.f, 0.f, 0.f);
+    EDMP_REP7(EDMP_DECL_RA)
+    EDMP_REP10(EDMP_DECL_RB)
+#define EDMP_LD_A(i) \
+    if constexpr (i < NA) ra##i = *reinterpret_cast<const float4*>(src_ + ag_ + i * Cs_);
+#define EDMP_LD_B(i) \
+    if constexpr (i < NB) rb##i = *reinterpret_cast<const float4*>(p.W + wg##i + wofs_);
+#define EDMP_ST_A(i) \
+    if constexpr (i < NA) *reinterpret_cast<float4*>(sn_ + i * (32 * LDK) + a_l) = ra##i;
+#define EDMP_ST_B(i) \
+    if constexpr (i < NB) *reinterpret_cast<float4*>(sn_ + bl##i) = rb##i;
+// fetch chunk `nc` (of the ch1 + ch2 channel chunks) into the staging registers
+#define EDMP_RCB_FETCH(nc)                                             \
+    {                                                                  \
+        const bool first_ = (nc) < ch1;                                \
+        const float* src_ = first_ ? p.src1 : p.src2;                  \
+        const int Cs_ = first_ ? p.C1 : p.C2;                          \
+        const int ci0_ = (first_ ? (nc) : (nc)-ch1) * KC;              \
+        const int ag_ = (first_ ? a_g1 : a_g2) + ci0_;                 \
+        const int wofs_ = (first_ ? 0 : p.C1) + ci0_;                  \
+        EDMP_REP7(EDMP_LD_A) EDMP_REP10(EDMP_LD_B)                     \
+    }
+#define EDMP_RCB_COMMIT(stage_ptr)                     \
+    {                                                  \
+        float* sn_ = (stage_ptr);                      \
+        EDMP_REP7(EDMP_ST_A) EDMP_REP10(EDMP_ST_B)     \
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+    // prologue: chunk 0 -> stage 0
+    EDMP_RCB_FETCH(0)
+    EDMP_RCB_COMMIT(lds)
+    __syncthreads();
+
+    const int frag = (lane & 31) * LDK + 4 * (lane >> 5);
+
+// all MFMAs of one K step for this wave's tiles, reading stage `st`
+#define EDMP_RCB_COMPUTE(st)                                                                                   \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                           \
+        const int j = wave + 4 * t;                                                                            \
+        if (j < NTILE) {                                                                                       \
+            const int l = j / S, s = j % S;                                                                    \
+            const int lp_lo = max(0, l - 2), lp_hi = min(L - 1, l + 2);                                        \
+            for (int lp = lp_lo; lp <= lp_hi; ++lp) {                                                          \
+                const int kt = lp - l + 2 - KT0;                                                               \
+                const float* a_s = (st) + lp * (32 * LDK) + frag;                                              \
+                const float* b_s = (st) + A_FL + (kt * CG + s * 32) * LDK + frag;                              \
+                _Pragma("unroll") for (int q = 0; q < KC / 8; ++q) {                                           \
+                    const float4 a4 = *reinterpret_cast<const float4*>(a_s + 8 * q);                           \
+                    const float4 b4 = *reinterpret_cast<const float4*>(b_s + 8 * q);                           \
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[t], 0, 0, 0);                \
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[t], 0, 0, 0);                \
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[t], 0, 0, 0);                \
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[t], 0, 0, 0);                \
+                }                                                                                              \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+
+    for (int kk = 0; kk < nK - 1; ++kk) {  // steady state: prefetch chunk kk+1 under the MFMAs of chunk kk
+        const int cur = kk & 1;
+        EDMP_RCB_FETCH(kk + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        const float* st = lds + cur * STAGE;
+        EDMP_RCB_COMPUTE(st)
+        __builtin_amdgcn_sched_barrier(0);
+        EDMP_RCB_COMMIT(lds + (cur ^ 1) * STAGE)
+        __syncthreads();
+    }
+    {
+        const float* st = lds + ((nK - 1) & 1) * STAGE;
+        EDMP_RCB_COMPUTE(st)
+    }
+#undef EDMP_RCB_COMPUTE
+#undef EDMP_RCB_FETCH
+#undef EDMP_RCB_COMMIT
+#undef EDMP_LD_A
+#undef EDMP_LD_B
+#undef EDMP_ST_A
+#undef EDMP_ST_B
+#undef EDMP_DECL_RA
+#undef EDMP_DECL_RB
+#undef EDMP_REP7
+#undef EDMP_REP10
+    __syncthreads();
+
+    // ---- epilogue: raw tile (+bias) -> LDS, per-sample statistics over the whole group, normalise, Mish, add, store
+    float* Y = lds;  // [32][YS]; all MFMA reads of the stages are complete (barrier above)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int j = wave + 4 * t;
+        if (j < NTILE) {
+            const int l = j / S, s = j % S;
+            const int cc = s * 32 + (lane & 31);
+            const float bias = p.bias[co0 + cc];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                Y[row * YS + l * CG + cc] = acc[t][r] + bias;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int row = tid >> 3, part = tid & 7;
+        const int b = b0 + row;
+        float4 v[NF4];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) {
+            v[i] = *reinterpret_cast<const float4*>(Y + row * YS + 4 * (part + 8 * i));
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        sum += __shfl_xor(sum, 4, 64);
+        constexpr float inv_n = 1.0f / (float)(L * CG);
+        const float mean = sum * inv_n;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) {
+            const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+            sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        sq += __shfl_xor(sq, 1, 64);
+        sq += __shfl_xor(sq, 2, 64);
+        sq += __shfl_xor(sq, 4, 64);
+        const float rstd = 1.0f / sqrtf(sq * inv_n + 1e-5f);
+        if (b < p.B) {
+#pragma unroll
+            for (int i = 0; i < NF4; ++i) {
+                const int col = 4 * (part + 8 * i);
+                const int l = col / CG, cc = col % CG;
+                const int ch = co0 + cc;
+                const float4 g4 = *reinterpret_cast<const float4*>(p.gamma + ch);
+                const float4 be4 = *reinterpret_cast<const float4*>(p.beta + ch);
+                float4 o;
+                {
+                    const float s0 = rstd * g4.x, s1 = rstd * g4.y, s2 = rstd * g4.z, s3 = rstd * g4.w;
+                    o.x = mish_fast(v[i].x * s0 + (be4.x - s0 * mean));
+                    o.y = mish_fast(v[i].y * s1 + (be4.y - s1 * mean));
+                    o.z = mish_fast(v[i].z * s2 + (be4.z - s2 * mean));
+                    o.w = mish_fast(v[i].w * s3 + (be4.w - s3 * mean));
+                }
+                const size_t gofs = ((size_t)b * L + l) * p.Cout + ch;
+                if (p.add_tb) {
+                    const float4 tb = *reinterpret_cast<const float4*>(p.add_tb + ch);
+                    o.x += tb.x;
+                    o.y += tb.y;
+                    o.z += tb.z;
+                    o.w += tb.w;
+                }
+                if (p.add_res) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.add_res + gofs);
+                    o.x += rr.x;
+                    o.y += rr.y;
+                    o.z += rr.z;
+                    o.w += rr.w;
+                }
+                *reinterpret_cast<float4*>(p.dst + gofs) = o;
+            }
+        }
+    }
+}
+
 // GroupNorm(8 groups, eps 1e-5, biased variance) -> Mish -> (+ time bias[c] | + residual[b,l,c]) in place.
 // One wave per (sample, group); the (C/8) x L elements of the group stay in registers between the passes.
 template <int EPL>  // elements per lane
@@ -498,6 +750,33 @@ static int launch_gn(const GnP& p, hipStream_t s) {
     return EDMP_OK;
 }
 
+template <int CG, int L>
+static int launch_rcb_t(const RcbP& p, hipStream_t s) {
+    static bool attr_set = false;
+    constexpr size_t bytes = RcbCfg<CG, L>::lds_bytes();
+    if (!attr_set) {
+        EDMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcb_conv_kernel<CG, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        attr_set = true;
+    }
+    dim3 grid(p.Cout / CG, (p.B + 31) / 32);
+    hipLaunchKernelGGL((rcb_conv_kernel<CG, L>), grid, dim3(256), bytes, s, p);
+    return EDMP_OK;
+}
+static bool rcb_supported(int cout, int L, int c1, int c2) {
+    const int cg = cout / 8;
+    const bool shape = (cg == 64 && (L == 2 || L == 4)) || (cg == 32 && (L == 4 || L == 7));
+    return shape && cout % 8 == 0 && c1 % 32 == 0 && c2 % 32 == 0;
+}
+static int launch_rcb(const RcbP& p, int L, hipStream_t s) {
+    const int cg = p.Cout / 8;
+    if (cg == 64 && L == 2) return launch_rcb_t<64, 2>(p, s);
+    if (cg == 64 && L == 4) return launch_rcb_t<64, 4>(p, s);
+    if (cg == 32 && L == 4) return launch_rcb_t<32, 4>(p, s);
+    if (cg == 32 && L == 7) return launch_rcb_t<32, 7>(p, s);
+    set_error("no fused conv+GroupNorm kernel for Cout=%d L=%d", p.Cout, L);
+    return EDMP_ERR_STATE;
+}
+
 void unet_destroy(UNet* u) {
     if (!u) return;
     if (u->wpack) (void)hipFree(u->wpack);
@@ -612,8 +891,10 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
         size_t gamma, beta;
         int tb_off;
         double fn, fe;
+        // fused conv+gn (OP_RCB): uses src1/src2/C1/C2/Lin/Cout/w/b/dst + gamma/beta/res/tb_off
     };
     std::vector<POp> pops;
+    const bool use_fused = getenv("EDMP_NO_FUSED") == nullptr;
     // concatenated time-MLP weights
     std::vector<float> tw_all, tb_all;
     int tb_cursor = 0;
@@ -682,6 +963,47 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
         tb_cursor += r.cout;
         tw_all.insert(tw_all.end(), params + r.tw.off, params + r.tw.off + (size_t)r.cout * td);
         tb_all.insert(tb_all.end(), params + r.tb.off, params + r.tb.off + r.cout);
+        auto emit_fused = [&](TH a, const TH* a2, int cin_true, size_t w, size_t b, size_t gamma, size_t beta, int res_buf, int tbo) {
+            POp o{};
+            o.kind = OP_RCB;
+            o.src1 = a.buf;
+            o.C1 = a.C;
+            o.src2 = a2 ? a2->buf : -1;
+            o.C2 = a2 ? a2->C : 0;
+            o.Lin = a.L;
+            o.Lout = a.L;
+            o.ntaps = 5;
+            o.Cout = r.cout;
+            o.w = w;
+            o.b = b;
+            o.gamma = gamma;
+            o.beta = beta;
+            o.res = res_buf;
+            o.tb_off = tbo;
+            o.dst = pool.get();
+            o.fn = 2.0 * a.L * r.cout * (double)cin_true * 5;
+            o.fe = 2.0 * (double)valid_pairs(a.L, a.L, 5, 1, 2, false) * r.cout * (double)(o.C1 + o.C2);
+            pops.push_back(o);
+            return TH{o.dst, r.cout, a.L};
+        };
+        if (use_fused && rcb_supported(r.cout, x.L, x.C, x2 ? x2->C : 0)) {
+            TH h = emit_fused(x, x2, r.cin, w1, b1, g1, be1, -1, tb_off);
+            int res_buf;
+            int rr_buf = -1;
+            if (r.has_res) {
+                size_t wr = pk.conv(params + r.rw.off, r.cout, r.cin, 1, cin_store);
+                size_t br = pk.vec(params + r.rb.off, r.cout);
+                TH rr = emit_conv(x, x2, r.cin, wr, br, r.cout, 1, 1, 0, false, x.L);
+                rr_buf = rr.buf;
+                res_buf = rr.buf;
+            } else {
+                res_buf = x2 ? -2 : x.buf;
+            }
+            TH out = emit_fused(h, nullptr, r.cout, w2, b2, g2, be2, res_buf, -1);
+            pool.put(h.buf);
+            if (rr_buf >= 0) pool.put(rr_buf);
+            return out;
+        }
         TH y1 = emit_conv(x, x2, r.cin, w1, b1, r.cout, 5, 1, 2, false, x.L);
         emit_gn(y1, g1, be1, -1, tb_off);
         TH y2 = emit_conv(y1, nullptr, r.cout, w2, b2, r.cout, 5, 1, 2, false, x.L);
@@ -768,11 +1090,11 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
     size_t o_tw = pk.vec(tw_all.data(), (int)tw_all.size()), o_tb = pk.vec(tb_all.data(), (int)tb_all.size());
     u->tb_stride = tb_cursor;
 
-    for (auto& o : pops) EDMP_REQUIRE(!(o.kind == OP_GN && o.res == -2), "identity residual over a channel concat is not supported");
+    for (auto& o : pops) EDMP_REQUIRE(!((o.kind == OP_GN || o.kind == OP_RCB) && o.res == -2), "identity residual over a channel concat is not supported");
     // allocate
     size_t max_lc = (size_t)N * CP0;
     for (auto& o : pops)
-        if (o.kind == OP_CONV) max_lc = std::max(max_lc, (size_t)o.Lout * o.Cout);
+        if (o.kind == OP_CONV || o.kind == OP_RCB) max_lc = std::max(max_lc, (size_t)o.Lout * o.Cout);
     u->buf_cap = max_lc * (size_t)max_batch;
     if (hipMalloc((void**)&u->wpack, pk.host.size() * sizeof(float)) != hipSuccess) {
         unet_destroy(u);
@@ -822,6 +1144,26 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
             op.flops_exec = o.fe;
             u->flops_nominal += o.fn;
             u->flops_exec += o.fe;
+        } else if (o.kind == OP_RCB) {
+            RcbP& c = op.rc;
+            c.src1 = u->bufs[o.src1];
+            c.src2 = o.src2 >= 0 ? u->bufs[o.src2] : nullptr;
+            c.C1 = o.C1;
+            c.C2 = o.C2;
+            c.W = u->wpack + o.w;
+            c.bias = u->wpack + o.b;
+            c.gamma = u->wpack + o.gamma;
+            c.beta = u->wpack + o.beta;
+            c.add_tb = nullptr;
+            c.add_res = o.res >= 0 ? u->bufs[o.res] : nullptr;
+            c.dst = u->bufs[o.dst];
+            c.Cout = o.Cout;
+            op.rc_L = o.Lin;
+            op.tb_off = o.tb_off;
+            op.flops_nominal = o.fn;
+            op.flops_exec = o.fe;
+            u->flops_nominal += o.fn;
+            u->flops_exec += o.fe;
         } else {
             GnP& g = op.gn;
             g.y = u->bufs[o.y];
@@ -863,7 +1205,28 @@ int unet_forward_impl(edmp_ctx* ctx, const float* x_dev, int B, int t, float* ep
     const float* trow = u->tbias + (size_t)(t - 1) * u->tb_stride;
     Prof& pf = ctx->prof;
     for (const Op& op : u->prog) {
-        if (op.kind == OP_CONV) {
+        if (op.kind == OP_RCB) {
+            RcbP p = op.rc;
+            p.B = B;
+            p.add_tb = op.tb_off >= 0 ? trow + op.tb_off : nullptr;
+            std::pair<hipEvent_t, hipEvent_t> ev{};
+            if (pf.on) {
+                if (!pf.pool.empty()) {
+                    ev = pf.pool.back();
+                    pf.pool.pop_back();
+                } else {
+                    EDMP_HIP_CHECK(hipEventCreate(&ev.first));
+                    EDMP_HIP_CHECK(hipEventCreate(&ev.second));
+                }
+                EDMP_HIP_CHECK(hipEventRecord(ev.first, s));
+            }
+            int rc = launch_rcb(p, op.rc_L, s);
+            if (rc) return rc;
+            if (pf.on) {
+                EDMP_HIP_CHECK(hipEventRecord(ev.second, s));
+                pf.pending.push_back(ev);
+            }
+        } else if (op.kind == OP_CONV) {
             ConvP p = op.cv;
             p.B = B;
             if (pf.on) {
