@@ -151,6 +151,7 @@ struct Op {
     GnP gn;
     RcbP rc;
     int rc_L;     // OP_RCB: positions
+    int rc_rows;  // OP_RCB: 0 = rcb_conv_kernel (wide levels), else rcb_rows_kernel variant
     int tb_off;   // GN: offset into the time-bias row, -1 if none
     double flops_nominal, flops_exec;  // CONV: per trajectory
 };
@@ -599,6 +600,269 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused Conv1dBlock of the NARROW levels (Cout <= 128, L in {7, 13, 25, 50}): same fusion as rcb_conv_kernel, other
+// shape.  Here the GEMM rows are (sample, position) pairs and the columns are channels: a workgroup owns SB whole
+// samples x CB channels (whole GroupNorm groups), stages the samples' input [SB][L+4 (zero halo)][KC] once per K step
+// and reads the 5 tap-shifted A operands of Conv1d(k=5, pad=2) straight out of that tile (row + tap) — no im2col, no
+// per-tap reload — against the [5][CB][KC] weight slab.  Statistics are complete in the workgroup; the raw conv output
+// never reaches HBM.  grid = (Cout/CB, B/SB).
+template <int CB, int L, int SB, int KC>
+struct RowsCfg {
+    static constexpr int LDK = KC + 4;
+    static constexpr int ROWS = SB * L;
+    static constexpr int MT = (ROWS + 31) / 32;
+    static constexpr int NT = CB / 32;
+    static constexpr int NTILE = MT * NT;
+    static constexpr int TPW = (NTILE + 3) / 4;
+    static constexpr int XR = SB * (L + 4);
+    static constexpr int A_FL = XR * LDK;
+    static constexpr int B_FL = 5 * CB * LDK;
+    static constexpr int STAGE = A_FL + B_FL;
+    static constexpr int A_F4 = ROWS * (KC / 4);
+    static constexpr int B_F4 = 5 * CB * (KC / 4);
+    static constexpr int NA = (A_F4 + 255) / 256;
+    static constexpr int NB = (B_F4 + 255) / 256;
+    static constexpr int YS = CB + 4;
+    static constexpr int Y_FL = MT * 32 * YS;
+    static constexpr int STAT_FL = 2 * SB * 16;
+    static constexpr size_t lds_bytes() {
+        size_t a = 2 * (size_t)STAGE * sizeof(float);
+        size_t b = ((size_t)Y_FL + STAT_FL) * sizeof(float);
+        return a > b ? a : b;
+    }
+};
+
+template <int CB, int L, int SB, int KC>
+__global__ __launch_bounds__(256) void rcb_rows_kernel(RcbP p) {
+    using Cf = RowsCfg<CB, L, SB, KC>;
+    constexpr int LDK = Cf::LDK, ROWS = Cf::ROWS, NT = Cf::NT, NTILE = Cf::NTILE, TPW = Cf::TPW;
+    constexpr int A_FL = Cf::A_FL, STAGE = Cf::STAGE, A_F4 = Cf::A_F4, B_F4 = Cf::B_F4, NA = Cf::NA, NB = Cf::NB;
+    constexpr int YS = Cf::YS, Y_FL = Cf::Y_FL, F4R = KC / 4;
+    static_assert(NA <= 4 && NB <= 10 && TPW <= 2, "staging macros cover NA <= 4, NB <= 10, two tiles per wave");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int co0 = blockIdx.x * CB;
+    const int b0 = blockIdx.y * SB;
+    const int Cin = p.C1 + p.C2;
+    const int ch1 = p.C1 / KC, ch2 = p.C2 / KC;
+    const int nK = ch1 + ch2;
+
+    // zero both A stages once: the 2+2 halo rows of every sample stay zero (= Conv1d's zero padding)
+    for (int i = tid; i < A_FL / 4; i += 256) {
+        *reinterpret_cast<float4*>(lds + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(lds + STAGE + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+#define EDMP_REP4(M) M(0) M(1) M(2) M(3)
+#define EDMP_REP10(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9)
+#define EDMP_DECL_XA(i)                                                                         \
+    const int fa##i = tid + i * 256;                                                            \
+    const bool pa##i = (i < NA) && (fa##i < A_F4);                                              \
+    const int ra_r##i = min(fa##i / F4R, ROWS - 1);                                             \
+    const int ga1_##i = (min(b0 + ra_r##i / L, p.B - 1) * L + ra_r##i % L) * p.C1 + (fa##i % F4R) * 4; \
+    const int ga2_##i = (min(b0 + ra_r##i / L, p.B - 1) * L + ra_r##i % L) * p.C2 + (fa##i % F4R) * 4; \
+    const int la##i = ((ra_r##i / L) * (L + 4) + ra_r##i % L + 2) * LDK + (fa##i % F4R) * 4;    \
+    float4 xa##i = make_float4(0.f, 0.f, 0.f, 0.f);
+#define EDMP_DECL_XB(i)                                                                         \
+    const int fb##i = tid + i * 256;                                                            \
+    const bool pb##i = (i < NB) && (fb##i < B_F4);                                              \
+    const int fbc##i = min(fb##i, B_F4 - 1);                                                    \
+    const int gb##i = ((fbc##i / (CB * F4R)) * p.Cout + co0 + (fbc##i % (CB * F4R)) / F4R) * Cin + (fbc##i % F4R) * 4; \
+    const int lb##i = A_FL + ((fbc##i / (CB * F4R)) * CB + (fbc##i % (CB * F4R)) / F4R) * LDK + (fbc##i % F4R) * 4;   \
+    float4 xb##i = make_float4(0.f, 0.f, 0.f, 0.f);
+    EDMP_REP4(EDMP_DECL_XA)
+    EDMP_REP10(EDMP_DECL_XB)
+#define EDMP_LD_XA(i) \
+    if (pa##i) xa##i = *reinterpret_cast<const float4*>(src_ + (first_ ? ga1_##i : ga2_##i) + ci0_);
+#define EDMP_LD_XB(i) \
+    if (pb##i) xb##i = *reinterpret_cast<const float4*>(p.W + gb##i + wofs_);
+#define EDMP_ST_XA(i) \
+    if (pa##i) *reinterpret_cast<float4*>(sn_ + la##i) = xa##i;
+#define EDMP_ST_XB(i) \
+    if (pb##i) *reinterpret_cast<float4*>(sn_ + lb##i) = xb##i;
+#define EDMP_ROWS_FETCH(nc)                                          \
+    {                                                                \
+        const bool first_ = (nc) < ch1;                              \
+        const float* src_ = first_ ? p.src1 : p.src2;                \
+        const int ci0_ = (first_ ? (nc) : (nc)-ch1) * KC;            \
+        const int wofs_ = (first_ ? 0 : p.C1) + ci0_;                \
+        EDMP_REP4(EDMP_LD_XA) EDMP_REP10(EDMP_LD_XB)                 \
+    }
+#define EDMP_ROWS_COMMIT(stage_ptr)                    \
+    {                                                  \
+        float* sn_ = (stage_ptr);                      \
+        EDMP_REP4(EDMP_ST_XA) EDMP_REP10(EDMP_ST_XB)   \
+    }
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        acc0[i] = 0.0f;
+        acc1[i] = 0.0f;
+    }
+    // this wave's tiles: j = wave + 4*t -> (row tile mt, channel tile nt)
+    const int j0 = wave, j1 = wave + 4;
+    const bool has0 = j0 < NTILE, has1 = (TPW > 1) && (j1 < NTILE);
+    const int fr = 4 * (lane >> 5);
+    const int r0 = min((j0 / NT) * 32 + (lane & 31), ROWS - 1);
+    const int r1 = min((j1 / NT) * 32 + (lane & 31), ROWS - 1);
+    const int arow0 = ((r0 / L) * (L + 4) + r0 % L) * LDK + fr;  // + tap*LDK
+    const int arow1 = ((r1 / L) * (L + 4) + r1 % L) * LDK + fr;
+    const int brow0 = A_FL + ((j0 % NT) * 32 + (lane & 31)) * LDK + fr;  // + tap*CB*LDK
+    const int brow1 = A_FL + ((j1 % NT) * 32 + (lane & 31)) * LDK + fr;
+
+    __syncthreads();  // halo zeros are in place before the first commit lands
+    EDMP_ROWS_FETCH(0)
+    EDMP_ROWS_COMMIT(lds)
+    __syncthreads();
+
+#define EDMP_ROWS_TILE(st, accv, arow, brow)                                                          \
+    _Pragma("unroll") for (int k = 0; k < 5; ++k) {                                                    \
+        const float* a_s = (st) + (arow) + k * LDK;                                                    \
+        const float* b_s = (st) + (brow) + k * (CB * LDK);                                             \
+        _Pragma("unroll") for (int q = 0; q < KC / 8; ++q) {                                           \
+            const float4 a4 = *reinterpret_cast<const float4*>(a_s + 8 * q);                           \
+            const float4 b4 = *reinterpret_cast<const float4*>(b_s + 8 * q);                           \
+            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, accv, 0, 0, 0);                    \
+            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, accv, 0, 0, 0);                    \
+            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, accv, 0, 0, 0);                    \
+            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, accv, 0, 0, 0);                    \
+        }                                                                                              \
+    }
+#define EDMP_ROWS_COMPUTE(st)                                    \
+    if (has0) { EDMP_ROWS_TILE(st, acc0, arow0, brow0) }         \
+    if (has1) { EDMP_ROWS_TILE(st, acc1, arow1, brow1) }
+
+    for (int kk = 0; kk < nK - 1; ++kk) {
+        const int cur = kk & 1;
+        EDMP_ROWS_FETCH(kk + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        const float* st = lds + cur * STAGE;
+        EDMP_ROWS_COMPUTE(st)
+        __builtin_amdgcn_sched_barrier(0);
+        EDMP_ROWS_COMMIT(lds + (cur ^ 1) * STAGE)
+        __syncthreads();
+    }
+    {
+        const float* st = lds + ((nK - 1) & 1) * STAGE;
+        EDMP_ROWS_COMPUTE(st)
+    }
+    __syncthreads();
+#undef EDMP_ROWS_COMPUTE
+#undef EDMP_ROWS_TILE
+#undef EDMP_ROWS_FETCH
+#undef EDMP_ROWS_COMMIT
+#undef EDMP_LD_XA
+#undef EDMP_LD_XB
+#undef EDMP_ST_XA
+#undef EDMP_ST_XB
+#undef EDMP_DECL_XA
+#undef EDMP_DECL_XB
+#undef EDMP_REP4
+#undef EDMP_REP10
+
+    // ---- epilogue: raw (+bias) -> LDS Y[row][channel]; per (sample, group) statistics; normalise, Mish, add, store
+    float* Y = lds;
+    float* stat = lds + Y_FL;  // [SB][16][2]
+    const int cg = p.Cout >> 3;       // channels per group (power of two)
+    const int cgs = __ffs(cg) - 1;    // log2(cg)
+    const int G = CB >> cgs;          // groups in this workgroup
+    {
+        const int cc = lane & 31;
+        if (has0) {
+            const int mt = j0 / NT, nt = j0 % NT;
+            const float bias = p.bias[co0 + nt * 32 + cc];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                Y[row * YS + nt * 32 + cc] = acc0[r] + bias;
+            }
+        }
+        if (has1) {
+            const int mt = j1 / NT, nt = j1 % NT;
+            const float bias = p.bias[co0 + nt * 32 + cc];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                Y[row * YS + nt * 32 + cc] = acc1[r] + bias;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        // 16 lanes per (sample, group) unit, two-pass statistics
+        const int l16 = tid & 15;
+        const int n = L << cgs;
+        const float inv_n = 1.0f / (float)n;
+        for (int u = tid >> 4; u < SB * G; u += 16) {
+            const int b = u / G, g = u - b * G;
+            const float* yb = Y + (b * L) * YS + (g << cgs);
+            float sum = 0.f;
+            for (int e = l16; e < n; e += 16) sum += yb[(e >> cgs) * YS + (e & (cg - 1))];
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            sum += __shfl_xor(sum, 4, 64);
+            sum += __shfl_xor(sum, 8, 64);
+            const float mean = sum * inv_n;
+            float sq = 0.f;
+            for (int e = l16; e < n; e += 16) {
+                const float d = yb[(e >> cgs) * YS + (e & (cg - 1))] - mean;
+                sq += d * d;
+            }
+            sq += __shfl_xor(sq, 1, 64);
+            sq += __shfl_xor(sq, 2, 64);
+            sq += __shfl_xor(sq, 4, 64);
+            sq += __shfl_xor(sq, 8, 64);
+            if (l16 == 0) {
+                stat[2 * (b * 16 + g)] = mean;
+                stat[2 * (b * 16 + g) + 1] = 1.0f / sqrtf(sq * inv_n + 1e-5f);
+            }
+        }
+    }
+    __syncthreads();
+    for (int f = tid; f < ROWS * (CB / 4); f += 256) {
+        const int r = f / (CB / 4), c4 = f % (CB / 4);
+        const int b = r / L, l = r % L;
+        if (b0 + b < p.B) {
+            const int cc = c4 * 4;
+            const int g = cc >> cgs;
+            const float mean = stat[2 * (b * 16 + g)], rstd = stat[2 * (b * 16 + g) + 1];
+            const int ch = co0 + cc;
+            const float4 v = *reinterpret_cast<const float4*>(Y + r * YS + cc);
+            const float4 g4 = *reinterpret_cast<const float4*>(p.gamma + ch);
+            const float4 be4 = *reinterpret_cast<const float4*>(p.beta + ch);
+            float4 o;
+            {
+                const float s0 = rstd * g4.x, s1 = rstd * g4.y, s2 = rstd * g4.z, s3 = rstd * g4.w;
+                o.x = mish_fast(v.x * s0 + (be4.x - s0 * mean));
+                o.y = mish_fast(v.y * s1 + (be4.y - s1 * mean));
+                o.z = mish_fast(v.z * s2 + (be4.z - s2 * mean));
+                o.w = mish_fast(v.w * s3 + (be4.w - s3 * mean));
+            }
+            const size_t gofs = ((size_t)(b0 + b) * L + l) * p.Cout + ch;
+            if (p.add_tb) {
+                const float4 tb = *reinterpret_cast<const float4*>(p.add_tb + ch);
+                o.x += tb.x;
+                o.y += tb.y;
+                o.z += tb.z;
+                o.w += tb.w;
+            }
+            if (p.add_res) {
+                const float4 rr = *reinterpret_cast<const float4*>(p.add_res + gofs);
+                o.x += rr.x;
+                o.y += rr.y;
+                o.z += rr.z;
+                o.w += rr.w;
+            }
+            *reinterpret_cast<float4*>(p.dst + gofs) = o;
+        }
+    }
+}
+
 // GroupNorm(8 groups, eps 1e-5, biased variance) -> Mish -> (+ time bias[c] | + residual[b,l,c]) in place.
 // One wave per (sample, group); the (C/8) x L elements of the group stay in registers between the passes.
 template <int EPL>  // elements per lane
@@ -766,6 +1030,42 @@ static bool rcb_supported(int cout, int L, int c1, int c2) {
     const int cg = cout / 8;
     const bool shape = (cg == 64 && (L == 2 || L == 4)) || (cg == 32 && (L == 4 || L == 7));
     return shape && cout % 8 == 0 && c1 % 32 == 0 && c2 % 32 == 0;
+}
+template <int CB, int L, int SB, int KC>
+static int launch_rows_t(const RcbP& p, hipStream_t s) {
+    static bool attr_set = false;
+    constexpr size_t bytes = RowsCfg<CB, L, SB, KC>::lds_bytes();
+    if (!attr_set) {
+        EDMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcb_rows_kernel<CB, L, SB, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        attr_set = true;
+    }
+    dim3 grid(p.Cout / CB, (p.B + SB - 1) / SB);
+    hipLaunchKernelGGL((rcb_rows_kernel<CB, L, SB, KC>), grid, dim3(256), bytes, s, p);
+    return EDMP_OK;
+}
+// narrow levels: (Cout, L) -> instance; input channels must be whole 32-chunks (or the padded 8-channel network input)
+static int rows_variant(int cout, int L, int c1, int c2) {
+    const bool k32 = c1 % 32 == 0 && c2 % 32 == 0 && c1 > 0;
+    const bool k8 = c1 == 8 && c2 == 0;
+    if (cout == 32 && L == 50) return k8 ? 1 : (k32 ? 2 : 0);
+    if (!k32) return 0;
+    if (cout == 32 && L == 25) return 3;
+    if (cout == 64 && L == 25) return 4;
+    if ((cout == 64 || cout == 128) && L == 13) return 5;
+    if (cout == 128 && L == 7) return 6;
+    return 0;
+}
+static int launch_rows(const RcbP& p, int variant, hipStream_t s) {
+    switch (variant) {
+        case 1: return launch_rows_t<32, 50, 2, 8>(p, s);
+        case 2: return launch_rows_t<32, 50, 2, 32>(p, s);
+        case 3: return launch_rows_t<32, 25, 5, 32>(p, s);
+        case 4: return launch_rows_t<64, 25, 5, 32>(p, s);
+        case 5: return launch_rows_t<64, 13, 4, 32>(p, s);
+        case 6: return launch_rows_t<64, 7, 9, 32>(p, s);
+    }
+    set_error("no narrow fused kernel variant %d", variant);
+    return EDMP_ERR_STATE;
 }
 static int launch_rcb(const RcbP& p, int L, hipStream_t s) {
     const int cg = p.Cout / 8;
@@ -948,6 +1248,29 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
         o.tb_off = tb_off;
         pops.push_back(o);
     };
+    auto emit_fused = [&](TH a, const TH* a2, int cin_true, int cout, size_t w, size_t b, size_t gamma, size_t beta, int res_buf, int tbo) {
+        POp o{};
+        o.kind = OP_RCB;
+        o.src1 = a.buf;
+        o.C1 = a.C;
+        o.src2 = a2 ? a2->buf : -1;
+        o.C2 = a2 ? a2->C : 0;
+        o.Lin = a.L;
+        o.Lout = a.L;
+        o.ntaps = 5;
+        o.Cout = cout;
+        o.w = w;
+        o.b = b;
+        o.gamma = gamma;
+        o.beta = beta;
+        o.res = res_buf;
+        o.tb_off = tbo;
+        o.dst = pool.get();
+        o.fn = 2.0 * a.L * cout * (double)cin_true * 5;
+        o.fe = 2.0 * (double)valid_pairs(a.L, a.L, 5, 1, 2, false) * cout * (double)(o.C1 + o.C2);
+        pops.push_back(o);
+        return TH{o.dst, cout, a.L};
+    };
     int rcb_idx = 0;
     auto emit_rcb = [&](TH x, const TH* x2) -> TH {
         const RawRCB& r = inv.rcbs[rcb_idx++];
@@ -963,31 +1286,8 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
         tb_cursor += r.cout;
         tw_all.insert(tw_all.end(), params + r.tw.off, params + r.tw.off + (size_t)r.cout * td);
         tb_all.insert(tb_all.end(), params + r.tb.off, params + r.tb.off + r.cout);
-        auto emit_fused = [&](TH a, const TH* a2, int cin_true, size_t w, size_t b, size_t gamma, size_t beta, int res_buf, int tbo) {
-            POp o{};
-            o.kind = OP_RCB;
-            o.src1 = a.buf;
-            o.C1 = a.C;
-            o.src2 = a2 ? a2->buf : -1;
-            o.C2 = a2 ? a2->C : 0;
-            o.Lin = a.L;
-            o.Lout = a.L;
-            o.ntaps = 5;
-            o.Cout = r.cout;
-            o.w = w;
-            o.b = b;
-            o.gamma = gamma;
-            o.beta = beta;
-            o.res = res_buf;
-            o.tb_off = tbo;
-            o.dst = pool.get();
-            o.fn = 2.0 * a.L * r.cout * (double)cin_true * 5;
-            o.fe = 2.0 * (double)valid_pairs(a.L, a.L, 5, 1, 2, false) * r.cout * (double)(o.C1 + o.C2);
-            pops.push_back(o);
-            return TH{o.dst, r.cout, a.L};
-        };
-        if (use_fused && rcb_supported(r.cout, x.L, x.C, x2 ? x2->C : 0)) {
-            TH h = emit_fused(x, x2, r.cin, w1, b1, g1, be1, -1, tb_off);
+        if (use_fused && (rcb_supported(r.cout, x.L, x.C, x2 ? x2->C : 0) || (rows_variant(r.cout, x.L, x.C, x2 ? x2->C : 0) && rows_variant(r.cout, x.L, r.cout, 0)))) {
+            TH h = emit_fused(x, x2, r.cin, r.cout, w1, b1, g1, be1, -1, tb_off);
             int res_buf;
             int rr_buf = -1;
             if (r.has_res) {
@@ -999,7 +1299,7 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
             } else {
                 res_buf = x2 ? -2 : x.buf;
             }
-            TH out = emit_fused(h, nullptr, r.cout, w2, b2, g2, be2, res_buf, -1);
+            TH out = emit_fused(h, nullptr, r.cout, r.cout, w2, b2, g2, be2, res_buf, -1);
             pool.put(h.buf);
             if (rr_buf >= 0) pool.put(rr_buf);
             return out;
@@ -1075,8 +1375,13 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
         size_t w = pk.conv(params + inv.final_cb.w.off, dm[1], dm[1], 5, dm[1]);
         size_t b = pk.vec(params + inv.final_cb.b.off, dm[1]);
         size_t g = pk.vec(params + inv.final_cb.gw.off, dm[1]), be = pk.vec(params + inv.final_cb.gb.off, dm[1]);
-        TH y = emit_conv(x, nullptr, dm[1], w, b, dm[1], 5, 1, 2, false, N);
-        emit_gn(y, g, be, -1, -1);
+        TH y;
+        if (use_fused && rows_variant(dm[1], N, x.C, 0)) {
+            y = emit_fused(x, nullptr, dm[1], dm[1], w, b, g, be, -1, -1);
+        } else {
+            y = emit_conv(x, nullptr, dm[1], w, b, dm[1], 5, 1, 2, false, N);
+            emit_gn(y, g, be, -1, -1);
+        }
         pool.put(x.buf);
         x = y;
     }
@@ -1159,6 +1464,7 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
             c.dst = u->bufs[o.dst];
             c.Cout = o.Cout;
             op.rc_L = o.Lin;
+            op.rc_rows = rcb_supported(o.Cout, o.Lin, o.C1, o.C2) ? 0 : rows_variant(o.Cout, o.Lin, o.C1, o.C2);
             op.tb_off = o.tb_off;
             op.flops_nominal = o.fn;
             op.flops_exec = o.fe;
@@ -1220,7 +1526,7 @@ int unet_forward_impl(edmp_ctx* ctx, const float* x_dev, int B, int t, float* ep
                 }
                 EDMP_HIP_CHECK(hipEventRecord(ev.first, s));
             }
-            int rc = launch_rcb(p, op.rc_L, s);
+            int rc = op.rc_rows ? launch_rows(p, op.rc_rows, s) : launch_rcb(p, op.rc_L, s);
             if (rc) return rc;
             if (pf.on) {
                 EDMP_HIP_CHECK(hipEventRecord(ev.second, s));

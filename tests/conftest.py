@@ -10,8 +10,25 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _effective_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:  # the oracle runs on torch-CPU: do not oversubscribe a quota-limited container (GPU boxes report 256 CPUs, grant 16)
+        import torch
+
+        torch.set_num_threads(_effective_cores())
+    except Exception:
+        pass
 
 
 def pytest_collection_modifyitems(config, items):

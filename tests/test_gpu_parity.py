@@ -101,6 +101,43 @@ def test_unet_vs_oracle_ragged_batches(oracle, tiny_net):
             assert rmse(a, b) <= 2e-5, (B, tt, rmse(a, b))
 
 
+def test_full_unet_fused_kernels_vs_oracle_ragged(oracle):
+    """Full-size net (the fused conv+GroupNorm kernels only exist for its channel widths), batch sizes that are
+    not multiples of any tile (32-sample / 2,4,5,9-sample workgroups), every level's activation checked."""
+    from edmp_amd import weights as W
+    from edmp_amd.temporalunet import TemporalUNet
+
+    sd = W.init_state_dict(11, 7, 32, FULL_DIMS)
+    net = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, state_dict=sd, max_batch=80)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    rs = np.random.RandomState(2)
+    for B in (1, 37, 67):
+        x = torch.tensor(rs.standard_normal((B, 7, 50)) * 1.5, dtype=torch.float32)
+        tr = {}
+        with torch.no_grad():
+            ref = oracle.unet_forward(tsd, x, torch.tensor([123.0]), trace=tr).numpy()
+        eps = net(x, torch.tensor([123.0])).cpu().numpy()
+        assert rmse(eps, ref) <= 2e-5 and maxabs(eps, ref) <= 2e-4, (B, rmse(eps, ref), maxabs(eps, ref))
+        for i in range(6):
+            assert maxabs(net.activation(i, B).cpu().numpy(), tr[f"down{i}"].numpy()) <= 5e-4, (B, f"down{i}")
+        assert maxabs(net.activation(100, B).cpu().numpy(), tr["mid"].numpy()) <= 5e-4
+        for j in range(5):
+            assert maxabs(net.activation(200 + j, B).cpu().numpy(), tr[f"up{j}"].numpy()) <= 5e-4, (B, f"up{j}")
+
+
+def test_fused_and_unfused_paths_agree(monkeypatch):
+    """EDMP_NO_FUSED=1 builds the same network from the generic conv + separate GroupNorm kernels."""
+    from edmp_amd import weights as W
+    from edmp_amd.temporalunet import TemporalUNet
+
+    sd = W.init_state_dict(12, 7, 32, FULL_DIMS)
+    x = torch.tensor(np.random.RandomState(4).standard_normal((33, 7, 50)), dtype=torch.float32)
+    a = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, state_dict=sd, max_batch=33)(x, torch.tensor([9.0])).cpu().numpy()
+    monkeypatch.setenv("EDMP_NO_FUSED", "1")
+    b = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, state_dict=sd, max_batch=33)(x, torch.tensor([9.0])).cpu().numpy()
+    assert rmse(a, b) <= 1e-5, rmse(a, b)
+
+
 def test_obstacle_table(golden):
     from edmp_amd.guide import IntersectionVolumeGuide
 
