@@ -40,6 +40,17 @@ def effective_cores() -> int:
     return max(1, n)
 
 
+def pmc_traffic():
+    """HBM MB per conv-family launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_hbm_traffic.json,
+    produced by scripts/pmc_unet_forward.py + scripts/summarize_pmc.py).  Counters cannot be read live in bench.py."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+            d = json.load(f)["conv_family"]
+        return {"hbm_MB_per_launch": d["hbm_MB_per_launch"], "hbm_bytes_per_traj_step": d["hbm_bytes_per_traj_step"], "source": "profiles/r01_pmc_hbm_traffic.json (PMC pass, not live)"}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,7 +166,7 @@ def main():
             "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s",
             "frac": ach / PEAK_F32_MFMA_TFLOPS,
-            "traffic": None,
+            "traffic": pmc_traffic(),
             "achieved_executed": conv_exec * B * T / (conv_ms * 1e-3) / 1e12,
             "launches": launches,
             "avg_launch_us": 1e3 * conv_ms / max(launches, 1),
