@@ -60,6 +60,8 @@ struct edmp_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;  // independent branch of the UNet (residual 1x1 convs) runs here
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     edmp::UNet* unet = nullptr;
     edmp::Guide* guide = nullptr;
     edmp::Sampler* sampler = nullptr;

@@ -181,6 +181,9 @@ extern "C" int edmp_ctx_create(int device, edmp_ctx** out) {
     edmp_ctx* c = new edmp_ctx();
     c->device = device;
     EDMP_HIP_CHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    EDMP_HIP_CHECK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    EDMP_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    EDMP_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     c->stream = c->own_stream;
     *out = c;
     return EDMP_OK;
@@ -201,6 +204,12 @@ extern "C" void edmp_ctx_destroy(edmp_ctx* ctx) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
+    if (ctx->side_stream) {
+        (void)hipStreamSynchronize(ctx->side_stream);
+        (void)hipStreamDestroy(ctx->side_stream);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -153,6 +153,7 @@ struct Op {
     int rc_L;     // OP_RCB: positions
     int rc_rows;  // OP_RCB: 0 = rcb_conv_kernel (wide levels), else rcb_rows_kernel variant
     int tb_off;   // GN: offset into the time-bias row, -1 if none
+    int branch;   // 0 = main stream; 1 = fork point (record before this op); 2 = runs on the side stream; 3 = join (wait) before this op
     double flops_nominal, flops_exec;  // CONV: per trajectory
 };
 
@@ -430,20 +431,30 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
 #define EDMP_DECL_RB(i)                                                                              \
     const int wg##i = ((KT0 + (tid + i * 256) / (CG * 8)) * p.Cout + co0 + (((tid + i * 256) % (CG * 8)) >> 3)) * Cin + sc4; \
     const int bl##i = A_FL + (((tid + i * 256) / (CG * 8)) * CG + (((tid + i * 256) % (CG * 8)) >> 3)) * LDK + sc4;          \
-    float4 rb##i = make_float4(0.f, 0.f, 0.f, 0.f);
-#define EDMP_DECL_RA(i) float4 ra##i = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 rbP##i = make_float4(0.f, 0.f, 0.f, 0.f), rbQ##i = make_float4(0.f, 0.f, 0.f, 0.f);
+#define EDMP_DECL_RA(i) float4 raP##i = make_float4(0.f, 0.f, 0.f, 0.f), raQ##i = make_float4(0.f, 0.f, 0.f, 0.f);
     EDMP_REP7(EDMP_DECL_RA)
     EDMP_REP10(EDMP_DECL_RB)
-#define EDMP_LD_A(i) \
-    if constexpr (i < NA) ra##i = *reinterpret_cast<const float4*>(src_ + ag_ + i * Cs_);
-#define EDMP_LD_B(i) \
-    if constexpr (i < NB) rb##i = *reinterpret_cast<const float4*>(p.W + wg##i + wofs_);
-#define EDMP_ST_A(i) \
-    if constexpr (i < NA) *reinterpret_cast<float4*>(sn_ + i * (32 * LDK) + a_l) = ra##i;
-#define EDMP_ST_B(i) \
-    if constexpr (i < NB) *reinterpret_cast<float4*>(sn_ + bl##i) = rb##i;
+#define EDMP_LD_AP(i) \
+    if constexpr (i < NA) raP##i = *reinterpret_cast<const float4*>(src_ + ag_ + i * Cs_);
+#define EDMP_LD_BP(i) \
+    if constexpr (i < NB) rbP##i = *reinterpret_cast<const float4*>(p.W + wg##i + wofs_);
+#define EDMP_ST_AP(i) \
+    if constexpr (i < NA) *reinterpret_cast<float4*>(sn_ + i * (32 * LDK) + a_l) = raP##i;
+#define EDMP_ST_BP(i) \
+    if constexpr (i < NB) *reinterpret_cast<float4*>(sn_ + bl##i) = rbP##i;
+#define EDMP_LD_AQ(i) \
+    if constexpr (i < NA) raQ##i = *reinterpret_cast<const float4*>(src_ + ag_ + i * Cs_);
+#define EDMP_LD_BQ(i) \
+    if constexpr (i < NB) rbQ##i = *reinterpret_cast<const float4*>(p.W + wg##i + wofs_);
+#define EDMP_ST_AQ(i) \
+    if constexpr (i < NA) *reinterpret_cast<float4*>(sn_ + i * (32 * LDK) + a_l) = raQ##i;
+#define EDMP_ST_BQ(i) \
+    if constexpr (i < NB) *reinterpret_cast<float4*>(sn_ + bl##i) = rbQ##i;
 // fetch chunk `nc` (of the ch1 + ch2 channel chunks) into the staging registers
-#define EDMP_RCB_FETCH(nc)                                             \
+// fetch channel chunk `nc` into register set P or Q (the K loop keeps TWO chunks in flight: first-touch activation
+// rows come from MALL/HBM at ~1 us, longer than one K step)
+#define EDMP_RCB_FETCH(SET, nc)                                        \
     {                                                                  \
         const bool first_ = (nc) < ch1;                                \
         const float* src_ = first_ ? p.src1 : p.src2;                  \
@@ -451,12 +462,12 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
         const int ci0_ = (first_ ? (nc) : (nc)-ch1) * KC;              \
         const int ag_ = (first_ ? a_g1 : a_g2) + ci0_;                 \
         const int wofs_ = (first_ ? 0 : p.C1) + ci0_;                  \
-        EDMP_REP7(EDMP_LD_A) EDMP_REP10(EDMP_LD_B)                     \
+        EDMP_REP7(EDMP_LD_A##SET) EDMP_REP10(EDMP_LD_B##SET)           \
     }
-#define EDMP_RCB_COMMIT(stage_ptr)                     \
-    {                                                  \
-        float* sn_ = (stage_ptr);                      \
-        EDMP_REP7(EDMP_ST_A) EDMP_REP10(EDMP_ST_B)     \
+#define EDMP_RCB_COMMIT(SET, stage_ptr)                        \
+    {                                                          \
+        float* sn_ = (stage_ptr);                              \
+        EDMP_REP7(EDMP_ST_A##SET) EDMP_REP10(EDMP_ST_B##SET)   \
     }
     f32x16 acc[NT];
 #pragma unroll
@@ -464,57 +475,82 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 
-    // prologue: chunk 0 -> stage 0
-    EDMP_RCB_FETCH(0)
-    EDMP_RCB_COMMIT(lds)
+    // prologue: chunk 0 -> stage 0, chunk 1 in flight in set Q
+    EDMP_RCB_FETCH(P, 0)
+    if (nK > 1) EDMP_RCB_FETCH(Q, 1)
+    EDMP_RCB_COMMIT(P, lds)
     __syncthreads();
 
     const int frag = (lane & 31) * LDK + 4 * (lane >> 5);
 
-// all MFMAs of one K step for this wave's tiles, reading stage `st`
+// all MFMAs of one K step for this wave's tiles, reading stage `st`.  The A/B fragments of the NEXT group of four
+// MFMAs are requested from LDS before the current four are issued (software pipelining by hand: one wave per SIMD
+// has nobody else to hide the ds_read latency).
 #define EDMP_RCB_COMPUTE(st)                                                                                   \
     _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                           \
         const int j = wave + 4 * t;                                                                            \
         if (j < NTILE) {                                                                                       \
             const int l = j / S, s = j % S;                                                                    \
             const int lp_lo = max(0, l - 2), lp_hi = min(L - 1, l + 2);                                        \
+            const float* a_s = (st) + lp_lo * (32 * LDK) + frag;                                               \
+            const float* b_s = (st) + A_FL + ((lp_lo - l + 2 - KT0) * CG + s * 32) * LDK + frag;               \
+            float4 a4 = *reinterpret_cast<const float4*>(a_s);                                                 \
+            float4 b4 = *reinterpret_cast<const float4*>(b_s);                                                 \
             for (int lp = lp_lo; lp <= lp_hi; ++lp) {                                                          \
-                const int kt = lp - l + 2 - KT0;                                                               \
-                const float* a_s = (st) + lp * (32 * LDK) + frag;                                              \
-                const float* b_s = (st) + A_FL + (kt * CG + s * 32) * LDK + frag;                              \
+                const int adv = (lp < lp_hi) ? 1 : 0;                                                          \
                 _Pragma("unroll") for (int q = 0; q < KC / 8; ++q) {                                           \
-                    const float4 a4 = *reinterpret_cast<const float4*>(a_s + 8 * q);                           \
-                    const float4 b4 = *reinterpret_cast<const float4*>(b_s + 8 * q);                           \
+                    const float* an = (q < KC / 8 - 1) ? a_s + 8 * (q + 1) : a_s + adv * (32 * LDK);           \
+                    const float* bn = (q < KC / 8 - 1) ? b_s + 8 * (q + 1) : b_s + adv * (CG * LDK);           \
+                    const float4 a4n = *reinterpret_cast<const float4*>(an);                                   \
+                    const float4 b4n = *reinterpret_cast<const float4*>(bn);                                   \
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[t], 0, 0, 0);                \
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[t], 0, 0, 0);                \
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[t], 0, 0, 0);                \
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[t], 0, 0, 0);                \
+                    a4 = a4n;                                                                                  \
+                    b4 = b4n;                                                                                  \
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); /* 2 ds_read (next fragments) ... */    \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); /* ... ahead of the 4 current MFMAs */  \
                 }                                                                                              \
+                a_s += 32 * LDK;                                                                               \
+                b_s += CG * LDK;                                                                               \
             }                                                                                                  \
         }                                                                                                      \
     }
 
-    for (int kk = 0; kk < nK - 1; ++kk) {  // steady state: prefetch chunk kk+1 under the MFMAs of chunk kk
-        const int cur = kk & 1;
-        EDMP_RCB_FETCH(kk + 1)
+    // steady state, unrolled by two so that the register sets alternate statically:
+    //   even step: MFMAs on stage 0 (chunk kk) | set Q (chunk kk+1) lands and is committed to stage 1 | set P fetches chunk kk+2
+    //   odd  step: MFMAs on stage 1 (chunk kk+1) | set P is committed to stage 0 | set Q fetches chunk kk+3
+    int kk = 0;
+    for (; kk + 1 < nK; kk += 2) {
+        if (kk + 2 < nK) EDMP_RCB_FETCH(P, kk + 2)
         __builtin_amdgcn_sched_barrier(0);
-        const float* st = lds + cur * STAGE;
-        EDMP_RCB_COMPUTE(st)
+        EDMP_RCB_COMPUTE(lds)
         __builtin_amdgcn_sched_barrier(0);
-        EDMP_RCB_COMMIT(lds + (cur ^ 1) * STAGE)
+        EDMP_RCB_COMMIT(Q, lds + STAGE)
+        __syncthreads();
+        if (kk + 3 < nK) EDMP_RCB_FETCH(Q, kk + 3)
+        __builtin_amdgcn_sched_barrier(0);
+        EDMP_RCB_COMPUTE(lds + STAGE)
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk + 2 < nK) EDMP_RCB_COMMIT(P, lds)
         __syncthreads();
     }
-    {
-        const float* st = lds + ((nK - 1) & 1) * STAGE;
-        EDMP_RCB_COMPUTE(st)
+    if (kk < nK) {  // odd chunk count: the last chunk sits in stage 0
+        EDMP_RCB_COMPUTE(lds)
+        __syncthreads();
     }
 #undef EDMP_RCB_COMPUTE
 #undef EDMP_RCB_FETCH
 #undef EDMP_RCB_COMMIT
-#undef EDMP_LD_A
-#undef EDMP_LD_B
-#undef EDMP_ST_A
-#undef EDMP_ST_B
+#undef EDMP_LD_AP
+#undef EDMP_LD_BP
+#undef EDMP_ST_AP
+#undef EDMP_ST_BP
+#undef EDMP_LD_AQ
+#undef EDMP_LD_BQ
+#undef EDMP_ST_AQ
+#undef EDMP_ST_BQ
 #undef EDMP_DECL_RA
 #undef EDMP_DECL_RB
 #undef EDMP_REP7
@@ -1191,10 +1227,12 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
         size_t gamma, beta;
         int tb_off;
         double fn, fe;
+        int branch;
         // fused conv+gn (OP_RCB): uses src1/src2/C1/C2/Lin/Cout/w/b/dst + gamma/beta/res/tb_off
     };
     std::vector<POp> pops;
     const bool use_fused = getenv("EDMP_NO_FUSED") == nullptr;
+    const bool use_side = getenv("EDMP_SIDE_STREAM") != nullptr;  // measured slower (event sync > overlap gain): opt-in
     // concatenated time-MLP weights
     std::vector<float> tw_all, tb_all;
     int tb_cursor = 0;
@@ -1291,15 +1329,19 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
             int res_buf;
             int rr_buf = -1;
             if (r.has_res) {
+                // the residual 1x1 conv only depends on the block input: it runs concurrently with conv1 on the side stream
                 size_t wr = pk.conv(params + r.rw.off, r.cout, r.cin, 1, cin_store);
                 size_t br = pk.vec(params + r.rb.off, r.cout);
+                if (use_side) pops.back().branch = 1;
                 TH rr = emit_conv(x, x2, r.cin, wr, br, r.cout, 1, 1, 0, false, x.L);
+                if (use_side) pops.back().branch = 2;
                 rr_buf = rr.buf;
                 res_buf = rr.buf;
             } else {
                 res_buf = x2 ? -2 : x.buf;
             }
             TH out = emit_fused(h, nullptr, r.cout, r.cout, w2, b2, g2, be2, res_buf, -1);
+            if (use_side && r.has_res) pops.back().branch = 3;
             pool.put(h.buf);
             if (rr_buf >= 0) pool.put(rr_buf);
             return out;
@@ -1429,6 +1471,7 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
         Op op{};
         op.kind = o.kind;
         op.tb_off = -1;
+        op.branch = o.branch;
         if (o.kind == OP_CONV) {
             ConvP& c = op.cv;
             c.src1 = u->bufs[o.src1];
@@ -1511,6 +1554,15 @@ int unet_forward_impl(edmp_ctx* ctx, const float* x_dev, int B, int t, float* ep
     const float* trow = u->tbias + (size_t)(t - 1) * u->tb_stride;
     Prof& pf = ctx->prof;
     for (const Op& op : u->prog) {
+        hipStream_t s = ctx->stream;
+        if (op.branch == 1) {
+            EDMP_HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
+        } else if (op.branch == 2) {
+            s = ctx->side_stream;
+            EDMP_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_fork, 0));
+        } else if (op.branch == 3) {
+            EDMP_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        }
         if (op.kind == OP_RCB) {
             RcbP p = op.rc;
             p.B = B;
@@ -1551,6 +1603,7 @@ int unet_forward_impl(edmp_ctx* ctx, const float* x_dev, int B, int t, float* ep
             } else {
                 launch_conv(p, s);
             }
+            if (op.branch == 2) EDMP_HIP_CHECK(hipEventRecord(ctx->ev_join, s));
         } else {
             GnP g = op.gn;
             g.B = B;
