@@ -20,6 +20,7 @@ void set_error(const char* fmt, ...) {
 
 // unet.hip / guide.hip
 int unet_forward_impl(edmp_ctx* ctx, const float* x_dev, int B, int t, float* eps_dev);
+int unet_run_program(edmp_ctx* ctx, int B, int t);
 int guide_raw_gradient_from_X(edmp_ctx* ctx, const double* X_dev, int B, int N, int t);
 int guide_set_startgoal(edmp_ctx* ctx, const double* start, const double* goal);
 const float* guide_graw(edmp_ctx* ctx);
@@ -64,16 +65,19 @@ __global__ void psample_kernel(double* __restrict__ X, const float* __restrict__
 // X[:, :, 1:-1] -= sched[:, t-1] * ((1-gn) g + gn g/||g||);  then X[:, :, 0] = start, X[:, :, -1] = goal
 __global__ void update_kernel(double* __restrict__ X, const float* __restrict__ graw, const double* __restrict__ sumsq,
                               const double* __restrict__ grad_norm, const double* __restrict__ sched, int sched_T, int t, int B, int C, int N,
-                              const double* __restrict__ sg, int guided, double* __restrict__ grad_out) {
+                              const double* __restrict__ sg, int guided, double* __restrict__ grad_out, float* __restrict__ xin) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * C * N) return;
     const int l = i % N;
     const int c = (i / N) % C;
     const int b = i / (N * C);
+    double xnew = X[i];
     if (l == 0) {
-        X[i] = sg[c];
+        xnew = sg[c];
+        X[i] = xnew;
     } else if (l == N - 1) {
-        X[i] = sg[7 + c];
+        xnew = sg[7 + c];
+        X[i] = xnew;
     } else if (guided) {
         const int L = N - 2;
         const size_t gi = ((size_t)b * C + c) * L + (l - 1);
@@ -81,8 +85,14 @@ __global__ void update_kernel(double* __restrict__ X, const float* __restrict__ 
         const float gv = graw[gi];
         const double gn = grad_norm[b];
         const double mixed = (1.0 - gn) * (double)gv + gn * (double)(gv / nrm);
-        X[i] = X[i] - sched[(size_t)b * sched_T + (t - 1)] * mixed;
+        xnew = xnew - sched[(size_t)b * sched_T + (t - 1)] * mixed;
+        X[i] = xnew;
         if (grad_out) grad_out[gi] = mixed;
+    }
+    if (xin) {  // next step's UNet input [B][N][8] (channel 7 is the zero pad, written by the c == 0 thread)
+        float* o = xin + ((size_t)b * N + l) * 8;
+        o[c] = (float)xnew;
+        if (c == 0) o[7] = 0.0f;
     }
 }
 
@@ -92,6 +102,74 @@ __global__ void condition_kernel(double* __restrict__ X, int B, int C, int N, co
     int c = i % C;
     X[(size_t)i * N] = sg[c];
     X[(size_t)i * N + N - 1] = sg[7 + c];
+}
+
+// X (B,C,N) f64 -> UNet input [B][N][8] f32 (channels >= C zero).  Thread per (b, l).
+__global__ void pack_state_kernel(const double* __restrict__ X, float* __restrict__ xin, int B, int C, int N) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * N) return;
+    const int b = i / N, l = i - b * N;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = (c < C) ? (float)X[((size_t)b * C + c) * N + l] : 0.0f;
+    float4* o = reinterpret_cast<float4*>(xin + (size_t)i * 8);
+    o[0] = make_float4(v[0], v[1], v[2], v[3]);
+    o[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// Tail of the denoiser + posterior step in one launch, thread per (sample, waypoint):
+//   eps[c] = final 1x1 conv of the UNet (final_conv.1, temporalunet.py:36) on h[b][l][0..Cin)
+//   X <- (X - c1 eps)/sqrt(alpha) + beta z                                   (diffusion.py:116-135)
+//   FINISH (steps without guidance): X[:, :, 0] = start, X[:, :, -1] = goal  (diffusion.py:347-349) and the next
+//   step's UNet input [B][N][8] f32 is written, so an unguided reverse step is exactly UNet + this kernel.
+template <bool FINISH>
+__global__ __launch_bounds__(256) void head_psample_kernel(const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ bias,
+                                                           double* __restrict__ X, const double* __restrict__ z, float* __restrict__ eps_out,
+                                                           float* __restrict__ xin, const double* __restrict__ sg, int B, int N, int Cin, int C,
+                                                           double c1, double sqrt_alpha, double beta, int zero_row0) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * N) return;
+    const int b = i / N, l = i - b * N;
+    const float* hp = h + (size_t)i * Cin;
+    float xo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // each thread's Cin inputs are read ONCE (float4) and reused by all C outputs; weights are wave-uniform (scalar loads)
+    float acc[8];
+#pragma unroll
+    for (int co = 0; co < 8; ++co) acc[co] = (co < C) ? bias[co] : 0.0f;
+    for (int c4 = 0; c4 < Cin; c4 += 4) {
+        const float4 hv = *reinterpret_cast<const float4*>(hp + c4);
+#pragma unroll
+        for (int co = 0; co < 8; ++co) {
+            if (co < C) {
+                const float* wr = w + co * Cin + c4;
+                acc[co] = fmaf(hv.x, wr[0], acc[co]);
+                acc[co] = fmaf(hv.y, wr[1], acc[co]);
+                acc[co] = fmaf(hv.z, wr[2], acc[co]);
+                acc[co] = fmaf(hv.w, wr[3], acc[co]);
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < 8; ++co) {
+        if (co >= C) break;
+        const float a = acc[co];
+        const size_t idx = ((size_t)b * C + co) * N + l;
+        if (eps_out) eps_out[idx] = a;
+        double zz = z[idx];
+        if (zero_row0 && b == 0) zz = 0.0;
+        double x = (X[idx] - c1 * (double)a) / sqrt_alpha + beta * zz;
+        if (FINISH) {
+            if (l == 0) x = sg[co];
+            if (l == N - 1) x = sg[7 + co];
+            xo[co] = (float)x;
+        }
+        X[idx] = x;
+    }
+    if (FINISH) {
+        float4* o = reinterpret_cast<float4*>(xin + (size_t)i * 8);
+        o[0] = make_float4(xo[0], xo[1], xo[2], xo[3]);
+        o[1] = make_float4(xo[4], xo[5], xo[6], xo[7]);
+    }
 }
 
 static int ensure_sampler_scratch(edmp_ctx* ctx, int n) {
@@ -124,37 +202,51 @@ static int set_startgoal(edmp_ctx* ctx, const double* start, const double* goal,
     return EDMP_OK;
 }
 
-static int step_a(edmp_ctx* ctx, double* X, const double* z, int B, int t, int zero_row0, int guided, float* eps_out, double* xpost_out) {
+// One reverse step, first half.  `fused` (the device-resident loop): the UNet input of this step already sits in
+// unet->x_in (written by the previous step's tail kernel) and, on steps without guidance, the tail kernel also applies
+// the start/goal conditioning and writes the next input.  Otherwise (teacher-forced API): X comes from the caller, is
+// packed here, and conditioning is left to step_b so that the un-conditioned posterior can be returned.
+static int step_a(edmp_ctx* ctx, double* X, const double* z, int B, int t, int zero_row0, int guided, float* eps_out, double* xpost_out,
+                  bool fused) {
     Sampler* s = ctx->sampler;
-    const int C = ctx->unet->desc.input_dim, N = ctx->unet->desc.horizon;
+    UNet* u = ctx->unet;
+    const int C = u->desc.input_dim, N = u->desc.horizon;
     const int n = B * C * N;
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(f64_to_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, st, X, s->x32, n);
-    int rc = unet_forward_impl(ctx, s->x32, B, t, s->eps);
+    const dim3 grid_bn((B * N + 255) / 256);
+    if (!fused) hipLaunchKernelGGL(pack_state_kernel, grid_bn, dim3(256), 0, st, X, u->x_in, B, C, N);
+    int rc = unet_run_program(ctx, B, t);
     if (rc) return rc;
-    if (eps_out) EDMP_HIP_CHECK(hipMemcpyAsync(eps_out, s->eps, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(psample_kernel, dim3((n + 255) / 256), dim3(256), 0, st, X, s->eps, z, n, C * N, s->c1[t - 1], s->sqrt_alpha[t - 1],
-                       s->beta[t - 1], (zero_row0 && t == 1) ? 1 : 0);
+    const bool g = guided && guided_step(t);
+    const int zr = (zero_row0 && t == 1) ? 1 : 0;
+    if (fused && !g) {
+        hipLaunchKernelGGL(head_psample_kernel<true>, grid_bn, dim3(256), 0, st, u->h_last, u->head_w, u->head_b, X, z, eps_out, u->x_in, s->sg, B, N,
+                           u->head_cin, C, s->c1[t - 1], s->sqrt_alpha[t - 1], s->beta[t - 1], zr);
+    } else {
+        hipLaunchKernelGGL(head_psample_kernel<false>, grid_bn, dim3(256), 0, st, u->h_last, u->head_w, u->head_b, X, z, eps_out, nullptr, s->sg, B, N,
+                           u->head_cin, C, s->c1[t - 1], s->sqrt_alpha[t - 1], s->beta[t - 1], zr);
+    }
     EDMP_HIP_CHECK(hipGetLastError());
     if (xpost_out) EDMP_HIP_CHECK(hipMemcpyAsync(xpost_out, X, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if (guided && guided_step(t)) {
+    if (g) {
         rc = guide_raw_gradient_from_X(ctx, X, B, N, t);
         if (rc) return rc;
     }
     return EDMP_OK;
 }
 
-static int step_b(edmp_ctx* ctx, double* X, int B, int t, int guided, double* grad_out) {
+static int step_b(edmp_ctx* ctx, double* X, int B, int t, int guided, double* grad_out, bool fused) {
     Sampler* s = ctx->sampler;
-    const int C = ctx->unet->desc.input_dim, N = ctx->unet->desc.horizon;
+    UNet* u = ctx->unet;
+    const int C = u->desc.input_dim, N = u->desc.horizon;
     hipStream_t st = ctx->stream;
     if (guided && guided_step(t)) {
         const int n = B * C * N;
         hipLaunchKernelGGL(update_kernel, dim3((n + 255) / 256), dim3(256), 0, st, X, guide_graw(ctx), guide_sumsq(ctx), guide_grad_norm(ctx),
-                           guide_sched(ctx), guide_rows_T(ctx), t, B, C, N, s->sg, 1, grad_out);
-    } else {
+                           guide_sched(ctx), guide_rows_T(ctx), t, B, C, N, s->sg, 1, grad_out, fused ? u->x_in : nullptr);
+    } else if (!fused) {
         hipLaunchKernelGGL(condition_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, X, B, C, N, s->sg);
-    }
+    }  // fused + unguided: head_psample_kernel<true> already conditioned X and wrote the next input
     EDMP_HIP_CHECK(hipGetLastError());
     return EDMP_OK;
 }
@@ -300,7 +392,7 @@ extern "C" int edmp_step_a_dev(edmp_ctx* ctx, double* X_dev, const double* z_dev
     if (rc) return rc;
     rc = set_startgoal(ctx, start, goal, true);
     if (rc) return rc;
-    return step_a(ctx, X_dev, z_dev, B, t, zero_row0, 1, eps_out_dev, xpost_out_dev);
+    return step_a(ctx, X_dev, z_dev, B, t, zero_row0, 1, eps_out_dev, xpost_out_dev, false);
 }
 
 extern "C" int edmp_step_b_dev(edmp_ctx* ctx, double* X_dev, int B, int t, const double* start, const double* goal, double* grad_out_dev) {
@@ -310,7 +402,7 @@ extern "C" int edmp_step_b_dev(edmp_ctx* ctx, double* X_dev, int B, int t, const
     EDMP_HIP_CHECK(hipSetDevice(ctx->device));
     rc = set_startgoal(ctx, start, goal, false);
     if (rc) return rc;
-    return step_b(ctx, X_dev, B, t, 1, grad_out_dev);
+    return step_b(ctx, X_dev, B, t, 1, grad_out_dev, false);
 }
 
 extern "C" double* edmp_sumsq_ptr_dev(edmp_ctx* ctx) { return ctx ? guide_sumsq(ctx) : nullptr; }
@@ -334,11 +426,12 @@ extern "C" int edmp_denoise_guided_dev(edmp_ctx* ctx, const double* noise_dev, i
     // X_T = noise[0] with start/goal conditioning                                       diffusion.py:303-307
     EDMP_HIP_CHECK(hipMemcpyAsync(s->X, noise_dev, n * sizeof(double), hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(condition_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, s->X, B, C, N, s->sg);
+    hipLaunchKernelGGL(pack_state_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, s->X, ctx->unet->x_in, B, C, N);
     for (int t = T; t > t_stop; --t) {
         const double* z = noise_dev + (size_t)(1 + (T - t)) * n;
-        rc = step_a(ctx, s->X, z, B, t, zero_row0, guided, nullptr, nullptr);
+        rc = step_a(ctx, s->X, z, B, t, zero_row0, guided, nullptr, nullptr, true);
         if (rc) return rc;
-        rc = step_b(ctx, s->X, B, t, guided, nullptr);
+        rc = step_b(ctx, s->X, B, t, guided, nullptr, true);
         if (rc) return rc;
     }
     EDMP_HIP_CHECK(hipMemcpyAsync(X_out_dev, s->X, n * sizeof(double), hipMemcpyDeviceToDevice, st));

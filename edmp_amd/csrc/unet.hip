@@ -1364,6 +1364,7 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
 
     TH x{pool.get(), CP0, N};
     const int x_in_buf = x.buf;
+    pool.pin(x_in_buf);  // written by the sampler kernels between forwards: never recycled as an activation
     std::vector<TH> skips;
     struct TapRec { int which; int buf, C, L; };
     std::vector<TapRec> tapr;
@@ -1540,17 +1541,13 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
 
 namespace edmp {
 // shared with sampler.hip: run the forward on the context's stream
-int unet_forward_impl(edmp_ctx* ctx, const float* x_dev, int B, int t, float* eps_dev) {
+// run the layer program on u->x_in ([B][N][8], already filled); leaves the head input in u->h_last
+int unet_run_program(edmp_ctx* ctx, int B, int t) {
     UNet* u = ctx->unet;
     EDMP_REQUIRE(u, "edmp_unet_load has not been called");
     EDMP_REQUIRE(B >= 1 && B <= u->max_batch, "batch %d outside 1..max_batch=%d", B, u->max_batch);
     EDMP_REQUIRE(t >= 1 && t <= u->desc.T, "t=%d outside 1..T=%d", t, u->desc.T);
     hipStream_t s = ctx->stream;
-    const int N = u->desc.horizon, C = u->desc.input_dim;
-    {
-        int total = B * N * 8;
-        hipLaunchKernelGGL(pack_input_kernel, dim3((total + 255) / 256), dim3(256), 0, s, x_dev, u->x_in, B, C, N, 8);
-    }
     const float* trow = u->tbias + (size_t)(t - 1) * u->tb_stride;
     Prof& pf = ctx->prof;
     for (const Op& op : u->prog) {
@@ -1612,6 +1609,22 @@ int unet_forward_impl(edmp_ctx* ctx, const float* x_dev, int B, int t, float* ep
             if (rc) return rc;
         }
     }
+    EDMP_HIP_CHECK(hipGetLastError());
+    return EDMP_OK;
+}
+
+int unet_forward_impl(edmp_ctx* ctx, const float* x_dev, int B, int t, float* eps_dev) {
+    UNet* u = ctx->unet;
+    EDMP_REQUIRE(u, "edmp_unet_load has not been called");
+    EDMP_REQUIRE(B >= 1 && B <= u->max_batch, "batch %d outside 1..max_batch=%d", B, u->max_batch);
+    hipStream_t s = ctx->stream;
+    const int N = u->desc.horizon, C = u->desc.input_dim;
+    {
+        int total = B * N * 8;
+        hipLaunchKernelGGL(pack_input_kernel, dim3((total + 255) / 256), dim3(256), 0, s, x_dev, u->x_in, B, C, N, 8);
+    }
+    int rc = unet_run_program(ctx, B, t);
+    if (rc) return rc;
     hipLaunchKernelGGL(head_1x1_kernel, dim3((B * N + 255) / 256), dim3(256), 0, s, u->h_last, u->head_w, u->head_b, eps_dev, B, N,
                        u->head_cin, C);
     EDMP_HIP_CHECK(hipGetLastError());
