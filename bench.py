@@ -148,6 +148,25 @@ def main():
             "unet_flops_per_traj_step": {"nominal": nominal, "executed_after_tap_skipping": executed, "survey": SURVEY_FLOPS_PER_TRAJ_STEP},
         }
 
+    # ---- informative: whole-scene wall time when the noise is NOT pre-resident (never `value`) -------------------------
+    if world == 1 and rank == 0:
+        def scene(**kw):
+            t1 = time.perf_counter()
+            X = dif.denoise_guided(net, guide, N, C, cfgs["guidance_schedule"], batch_size=B, start=start, goal=goal, return_device=True, **kw)
+            guide.row_swept_volumes(start, goal, X)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1
+
+        np.random.seed(0)
+        t_np = scene()                      # reference contract: NumPy draw (91 M normals) + 734 MB upload + loop
+        t_dev = scene(noise="device", seed=1)  # non-parity mode: Philox on the GPU
+        out["end_to_end_scene_seconds"] = {
+            "noise_resident_in_hbm": dt / args.steps,
+            "numpy_stream_drawn_and_uploaded_per_scene": t_np,
+            "device_philox_noise": t_dev,
+            "traj_steps_per_s": {"numpy_stream": B * T / t_np, "device_noise": B * T / t_dev},
+        }
+
     # ---- roofline of the dominant kernel family (fp32-MFMA implicit-GEMM conv), N=1 only -------------------------
     if world == 1 and rank == 0 and not args.no_roofline:
         ctx.prof(True)

@@ -104,6 +104,82 @@ __global__ void condition_kernel(double* __restrict__ X, int B, int C, int N, co
     X[(size_t)i * N + N - 1] = sg[7 + c];
 }
 
+// ---- device noise source (NOT the reference's NumPy stream: a separate, explicitly non-parity mode) --------------------
+// Philox4x32-10 counter RNG (Salmon et al. 2011): counter = (element, step, block, 0), key = seed.  Eight standard
+// normals per (sample, waypoint) and step via Box-Muller, one per joint channel.  Removes the 0.9 s host draw and the
+// 734 MB upload per scene that the NumPy-stream contract costs.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+        c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = c2;
+    out[3] = c3;
+}
+
+__device__ __forceinline__ void rng_normal8(uint64_t seed, uint32_t step, uint32_t elem, float (&z)[8]) {
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        uint32_t u[4];
+        philox4x32_10(elem, step, (uint32_t)blk, 0u, k0, k1, u);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u1 = ((float)u[2 * h] + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]
+            const float u2 = (float)u[2 * h + 1] * 2.3283064365386963e-10f;       // [0, 1)
+            const float r = sqrtf(-2.0f * logf(u1));
+            float sn, cs;
+            sincospif(2.0f * u2, &sn, &cs);
+            z[4 * blk + 2 * h] = r * cs;
+            z[4 * blk + 2 * h + 1] = r * sn;
+        }
+    }
+}
+
+// the z tensor (B,C,N) f64 the loop uses at `step` (0 = initial state, 1 + T - t = reverse step t): tests / inspection
+__global__ void rng_normal_kernel(uint64_t seed, int step, double* __restrict__ out, int B, int C, int N) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * N) return;
+    const int b = i / N, l = i - b * N;
+    float z[8];
+    rng_normal8(seed, (uint32_t)step, (uint32_t)i, z);
+    for (int c = 0; c < C && c < 8; ++c) out[((size_t)b * C + c) * N + l] = (double)z[c];
+}
+
+// X_T = N(0, I) with start/goal conditioning, plus the first UNet input              (diffusion.py:303-307)
+__global__ void init_state_rng_kernel(uint64_t seed, double* __restrict__ X, float* __restrict__ xin, const double* __restrict__ sg, int B, int C,
+                                      int N) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * N) return;
+    const int b = i / N, l = i - b * N;
+    float z[8];
+    rng_normal8(seed, 0u, (uint32_t)i, z);
+    float xo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C && c < 8; ++c) {
+        double x = (double)z[c];
+        if (l == 0) x = sg[c];
+        if (l == N - 1) x = sg[7 + c];
+        X[((size_t)b * C + c) * N + l] = x;
+        xo[c] = (float)x;
+    }
+    float4* o = reinterpret_cast<float4*>(xin + (size_t)i * 8);
+    o[0] = make_float4(xo[0], xo[1], xo[2], xo[3]);
+    o[1] = make_float4(xo[4], xo[5], xo[6], xo[7]);
+}
+
 // X (B,C,N) f64 -> UNet input [B][N][8] f32 (channels >= C zero).  Thread per (b, l).
 __global__ void pack_state_kernel(const double* __restrict__ X, float* __restrict__ xin, int B, int C, int N) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -122,16 +198,18 @@ __global__ void pack_state_kernel(const double* __restrict__ X, float* __restric
 //   X <- (X - c1 eps)/sqrt(alpha) + beta z                                   (diffusion.py:116-135)
 //   FINISH (steps without guidance): X[:, :, 0] = start, X[:, :, -1] = goal  (diffusion.py:347-349) and the next
 //   step's UNet input [B][N][8] f32 is written, so an unguided reverse step is exactly UNet + this kernel.
-template <bool FINISH>
+template <bool FINISH, bool RNG>
 __global__ __launch_bounds__(256) void head_psample_kernel(const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ bias,
                                                            double* __restrict__ X, const double* __restrict__ z, float* __restrict__ eps_out,
                                                            float* __restrict__ xin, const double* __restrict__ sg, int B, int N, int Cin, int C,
-                                                           double c1, double sqrt_alpha, double beta, int zero_row0) {
+                                                           double c1, double sqrt_alpha, double beta, int zero_row0, uint64_t seed, int rng_step) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * N) return;
     const int b = i / N, l = i - b * N;
     const float* hp = h + (size_t)i * Cin;
     float xo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float zr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (RNG) rng_normal8(seed, (uint32_t)rng_step, (uint32_t)i, zr);
     // each thread's Cin inputs are read ONCE (float4) and reused by all C outputs; weights are wave-uniform (scalar loads)
     float acc[8];
 #pragma unroll
@@ -155,7 +233,7 @@ __global__ __launch_bounds__(256) void head_psample_kernel(const float* __restri
         const float a = acc[co];
         const size_t idx = ((size_t)b * C + co) * N + l;
         if (eps_out) eps_out[idx] = a;
-        double zz = z[idx];
+        double zz = RNG ? (double)zr[co] : z[idx];
         if (zero_row0 && b == 0) zz = 0.0;
         double x = (X[idx] - c1 * (double)a) / sqrt_alpha + beta * zz;
         if (FINISH) {
@@ -207,7 +285,7 @@ static int set_startgoal(edmp_ctx* ctx, const double* start, const double* goal,
 // the start/goal conditioning and writes the next input.  Otherwise (teacher-forced API): X comes from the caller, is
 // packed here, and conditioning is left to step_b so that the un-conditioned posterior can be returned.
 static int step_a(edmp_ctx* ctx, double* X, const double* z, int B, int t, int zero_row0, int guided, float* eps_out, double* xpost_out,
-                  bool fused) {
+                  bool fused, bool use_rng = false, uint64_t seed = 0) {
     Sampler* s = ctx->sampler;
     UNet* u = ctx->unet;
     const int C = u->desc.input_dim, N = u->desc.horizon;
@@ -219,13 +297,16 @@ static int step_a(edmp_ctx* ctx, double* X, const double* z, int B, int t, int z
     if (rc) return rc;
     const bool g = guided && guided_step(t);
     const int zr = (zero_row0 && t == 1) ? 1 : 0;
+    const int rstep = 1 + (s->T - t);
+#define EDMP_HP_ARGS(xin_ptr) u->h_last, u->head_w, u->head_b, X, z, eps_out, (xin_ptr), s->sg, B, N, u->head_cin, C, s->c1[t - 1], s->sqrt_alpha[t - 1], s->beta[t - 1], zr, seed, rstep
     if (fused && !g) {
-        hipLaunchKernelGGL(head_psample_kernel<true>, grid_bn, dim3(256), 0, st, u->h_last, u->head_w, u->head_b, X, z, eps_out, u->x_in, s->sg, B, N,
-                           u->head_cin, C, s->c1[t - 1], s->sqrt_alpha[t - 1], s->beta[t - 1], zr);
+        if (use_rng) hipLaunchKernelGGL((head_psample_kernel<true, true>), grid_bn, dim3(256), 0, st, EDMP_HP_ARGS(u->x_in));
+        else hipLaunchKernelGGL((head_psample_kernel<true, false>), grid_bn, dim3(256), 0, st, EDMP_HP_ARGS(u->x_in));
     } else {
-        hipLaunchKernelGGL(head_psample_kernel<false>, grid_bn, dim3(256), 0, st, u->h_last, u->head_w, u->head_b, X, z, eps_out, nullptr, s->sg, B, N,
-                           u->head_cin, C, s->c1[t - 1], s->sqrt_alpha[t - 1], s->beta[t - 1], zr);
+        if (use_rng) hipLaunchKernelGGL((head_psample_kernel<false, true>), grid_bn, dim3(256), 0, st, EDMP_HP_ARGS((float*)nullptr));
+        else hipLaunchKernelGGL((head_psample_kernel<false, false>), grid_bn, dim3(256), 0, st, EDMP_HP_ARGS((float*)nullptr));
     }
+#undef EDMP_HP_ARGS
     EDMP_HIP_CHECK(hipGetLastError());
     if (xpost_out) EDMP_HIP_CHECK(hipMemcpyAsync(xpost_out, X, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (g) {
@@ -407,11 +488,11 @@ extern "C" int edmp_step_b_dev(edmp_ctx* ctx, double* X_dev, int B, int t, const
 
 extern "C" double* edmp_sumsq_ptr_dev(edmp_ctx* ctx) { return ctx ? guide_sumsq(ctx) : nullptr; }
 
-extern "C" int edmp_denoise_guided_dev(edmp_ctx* ctx, const double* noise_dev, int B, const double* start, const double* goal, int guided,
-                                       int t_stop, int zero_row0, double* X_out_dev) {
+static int denoise_loop(edmp_ctx* ctx, const double* noise_dev, bool use_rng, uint64_t seed, int B, const double* start, const double* goal,
+                        int guided, int t_stop, int zero_row0, double* X_out_dev) {
     int rc = check_loop_state(ctx, B, guided != 0);
     if (rc) return rc;
-    EDMP_REQUIRE(noise_dev && start && goal && X_out_dev, "null pointer");
+    EDMP_REQUIRE((noise_dev || use_rng) && start && goal && X_out_dev, "null pointer");
     Sampler* s = ctx->sampler;
     const int T = s->T;
     EDMP_REQUIRE(t_stop >= 0 && t_stop < T, "t_stop out of range");
@@ -423,18 +504,41 @@ extern "C" int edmp_denoise_guided_dev(edmp_ctx* ctx, const double* noise_dev, i
     rc = set_startgoal(ctx, start, goal, guided != 0);
     if (rc) return rc;
     hipStream_t st = ctx->stream;
-    // X_T = noise[0] with start/goal conditioning                                       diffusion.py:303-307
-    EDMP_HIP_CHECK(hipMemcpyAsync(s->X, noise_dev, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(condition_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, s->X, B, C, N, s->sg);
-    hipLaunchKernelGGL(pack_state_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, s->X, ctx->unet->x_in, B, C, N);
+    // X_T with start/goal conditioning                                                  diffusion.py:303-307
+    if (use_rng) {
+        hipLaunchKernelGGL(init_state_rng_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, seed, s->X, ctx->unet->x_in, s->sg, B, C, N);
+    } else {
+        EDMP_HIP_CHECK(hipMemcpyAsync(s->X, noise_dev, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(condition_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, s->X, B, C, N, s->sg);
+        hipLaunchKernelGGL(pack_state_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, s->X, ctx->unet->x_in, B, C, N);
+    }
     for (int t = T; t > t_stop; --t) {
-        const double* z = noise_dev + (size_t)(1 + (T - t)) * n;
-        rc = step_a(ctx, s->X, z, B, t, zero_row0, guided, nullptr, nullptr, true);
+        const double* z = use_rng ? nullptr : noise_dev + (size_t)(1 + (T - t)) * n;
+        rc = step_a(ctx, s->X, z, B, t, zero_row0, guided, nullptr, nullptr, true, use_rng, seed);
         if (rc) return rc;
         rc = step_b(ctx, s->X, B, t, guided, nullptr, true);
         if (rc) return rc;
     }
     EDMP_HIP_CHECK(hipMemcpyAsync(X_out_dev, s->X, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return EDMP_OK;
+}
+
+extern "C" int edmp_denoise_guided_dev(edmp_ctx* ctx, const double* noise_dev, int B, const double* start, const double* goal, int guided,
+                                       int t_stop, int zero_row0, double* X_out_dev) {
+    EDMP_REQUIRE(noise_dev, "edmp_denoise_guided_dev: noise_dev is NULL (use edmp_denoise_guided_rng_dev for the device noise source)");
+    return denoise_loop(ctx, noise_dev, false, 0, B, start, goal, guided, t_stop, zero_row0, X_out_dev);
+}
+
+extern "C" int edmp_denoise_guided_rng_dev(edmp_ctx* ctx, uint64_t seed, int B, const double* start, const double* goal, int guided, int t_stop,
+                                           int zero_row0, double* X_out_dev) {
+    return denoise_loop(ctx, nullptr, true, seed, B, start, goal, guided, t_stop, zero_row0, X_out_dev);
+}
+
+extern "C" int edmp_rng_normal_dev(edmp_ctx* ctx, uint64_t seed, int step_index, int B, int C, int N, double* out_dev) {
+    EDMP_REQUIRE(ctx && out_dev && B >= 1 && C >= 1 && C <= 8 && N >= 1 && step_index >= 0, "edmp_rng_normal_dev: bad arguments");
+    EDMP_HIP_CHECK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(rng_normal_kernel, dim3((B * N + 255) / 256), dim3(256), 0, ctx->stream, seed, step_index, out_dev, B, C, N);
+    EDMP_HIP_CHECK(hipGetLastError());
     return EDMP_OK;
 }
 

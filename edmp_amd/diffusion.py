@@ -68,21 +68,31 @@ class Diffusion:
             guide._set_rows(guidance_schedule if guidance_schedule is not None else guide._sched)
 
     def denoise_guided(self, model, guide, traj_len, num_channels, guidance_schedule, batch_size=1, start=None, goal=None,
-                       condition=True, benchmarking=False, *, noise=None, t_stop=0, zero_row0=True, return_device=False):
+                       condition=True, benchmarking=False, *, noise=None, seed=0, t_stop=0, zero_row0=True, return_device=False):
         """diffusion.py:300-356.  ``noise``: optional pre-drawn (T+1,B,C,N) f64 ndarray / device tensor (default:
-        drawn from the global NumPy RNG in the reference's order).  Returns (B,C,N) f64 ndarray (a fresh copy)."""
+        drawn from the global NumPy RNG in the reference's order); ``noise="device"`` draws z on the GPU (Philox,
+        ``seed``) — a non-parity mode without the host draw / upload.  Returns (B,C,N) f64 ndarray (a fresh copy)."""
         if not condition:
             raise NotImplementedError("the reference driver always conditions on start/goal (infer_serial.py:139)")
         ctx = self.ctx
         self._prepare(model, guide, batch_size, guidance_schedule)
+        s = np.ascontiguousarray(np.asarray(start, dtype=np.float64).reshape(-1))
+        g = np.ascontiguousarray(np.asarray(goal, dtype=np.float64).reshape(-1))
+        out = ctx.empty((batch_size, num_channels, traj_len), torch.float64)
+        if isinstance(noise, str):
+            if noise != "device":
+                raise ValueError("noise must be an array, a device tensor, None (NumPy stream) or 'device'")
+            _capi.check(
+                ctx.lib.edmp_denoise_guided_rng_dev(ctx.h, int(seed) & 0xFFFFFFFFFFFFFFFF, batch_size, _capi.as_pd(s), _capi.as_pd(g),
+                                                    1 if guide is not None else 0, int(t_stop), 1 if zero_row0 else 0, ptr(out)),
+                "edmp_denoise_guided_rng_dev",
+            )
+            return out if return_device else ctx.to_host(out)
         if noise is None:
             noise = draw_noise(self.T, batch_size, num_channels, traj_len)
         nd = noise if (isinstance(noise, torch.Tensor) and noise.is_cuda) else ctx.to_dev(noise, torch.float64)
         if tuple(nd.shape) != (self.T + 1, batch_size, num_channels, traj_len) or nd.dtype != torch.float64:
             raise ValueError(f"noise must be f64 {(self.T + 1, batch_size, num_channels, traj_len)}, got {tuple(nd.shape)} {nd.dtype}")
-        s = np.ascontiguousarray(np.asarray(start, dtype=np.float64).reshape(-1))
-        g = np.ascontiguousarray(np.asarray(goal, dtype=np.float64).reshape(-1))
-        out = ctx.empty((batch_size, num_channels, traj_len), torch.float64)
         _capi.check(
             ctx.lib.edmp_denoise_guided_dev(ctx.h, ptr(nd), batch_size, _capi.as_pd(s), _capi.as_pd(g), 1 if guide is not None else 0, int(t_stop),
                                             1 if zero_row0 else 0, ptr(out)),
@@ -117,6 +127,13 @@ class Diffusion:
             allreduce(self.sumsq_tensor())
         _capi.check(ctx.lib.edmp_step_b_dev(ctx.h, ptr(Xd), B, int(t), _capi.as_pd(s), _capi.as_pd(g), ptr(grad)), "edmp_step_b_dev")
         return dict(eps=ctx.to_host(eps), x_post=ctx.to_host(xpost), grad=ctx.to_host(grad) if guided else None, x_out=ctx.to_host(Xd))
+
+    def device_noise(self, seed, step_index, batch_size, num_channels=7, traj_len=50) -> np.ndarray:
+        """the (B,C,N) z tensor of ``noise="device"`` at step_index (0 = X_T, 1 + T - t = reverse step t)."""
+        ctx = self.ctx
+        out = ctx.empty((batch_size, num_channels, traj_len), torch.float64)
+        _capi.check(ctx.lib.edmp_rng_normal_dev(ctx.h, int(seed) & 0xFFFFFFFFFFFFFFFF, int(step_index), batch_size, num_channels, traj_len, ptr(out)))
+        return ctx.to_host(out)
 
     def sumsq_tensor(self) -> torch.Tensor:
         """zero-copy f64 view of the device scalar holding sum(g^2) of the last guided step."""

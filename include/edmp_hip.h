@@ -128,6 +128,15 @@ double* edmp_sumsq_ptr_dev(edmp_ctx* ctx);
 int edmp_denoise_guided_dev(edmp_ctx* ctx, const double* noise_dev, int B, const double* start, const double* goal,
                             int guided, int t_stop, int zero_row0, double* X_out_dev);
 
+/* Device noise source — explicitly NOT the reference's NumPy RandomState stream (that contract is served by
+ * edmp_denoise_guided_dev): Philox4x32-10 counter RNG + Box-Muller inside the sampler kernels, no noise tensor, no
+ * host draw, no upload.  Same loop otherwise (replaces diffusion.py:300-356 with z ~ N(0, I) drawn on the GPU).
+ * edmp_rng_normal_dev materialises the z tensor (B,C,N) f64 the loop uses at step_index (0 = initial X_T,
+ * 1 + T - t = reverse step t) so the two entry points can be cross-checked. */
+int edmp_denoise_guided_rng_dev(edmp_ctx* ctx, uint64_t seed, int B, const double* start, const double* goal, int guided,
+                                int t_stop, int zero_row0, double* X_out_dev);
+int edmp_rng_normal_dev(edmp_ctx* ctx, uint64_t seed, int step_index, int B, int C, int N, double* out_dev);
+
 /* ---- instrumentation ----------------------------------------------------------------------------------- */
 /* accumulate HIP-event time of the dominant kernel family (the MFMA conv kernels) while enabled */
 int edmp_prof_enable(edmp_ctx* ctx, int on);

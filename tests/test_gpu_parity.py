@@ -350,3 +350,38 @@ def test_infer_serial_driver_c1():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = infer_serial.run(os.path.join(root, "configs", "cfg_c1_plumbing.yaml"), verbose=False)
     assert len(res) == 1 and res[0]["trajectory"].shape == (7, 50) and np.isfinite(res[0]["trajectory"]).all()
+
+
+def test_device_noise_mode(tiny_net):
+    """noise="device" (Philox on the GPU, explicitly non-parity): statistics of the stream, determinism, seed / step
+    independence, and the loop driven by it equals the loop driven by the materialised stream."""
+    from edmp_amd import scenes
+    from edmp_amd.diffusion import Diffusion
+    from edmp_amd.guide import IntersectionVolumeGuide
+
+    net, _ = tiny_net
+    dif = Diffusion(T, DEV)
+    B = 64
+    z = np.stack([dif.device_noise(7, s, B) for s in range(40)])  # 40 x 64 x 7 x 50 = 896k samples
+    assert abs(z.mean()) < 5e-3 and abs(z.var() - 1.0) < 1e-2
+    assert abs(np.mean(z**3)) < 2e-2 and abs(np.mean(z**4) - 3.0) < 6e-2
+    assert np.abs(z).max() < 7.0
+    # no correlation between channels / steps / neighbours
+    assert abs(np.corrcoef(z[:, :, 0].ravel(), z[:, :, 1].ravel())[0, 1]) < 1e-2
+    assert abs(np.corrcoef(z[0].ravel(), z[1].ravel())[0, 1]) < 2e-2
+    assert abs(np.corrcoef(z[..., :-1].ravel(), z[..., 1:].ravel())[0, 1]) < 5e-3
+    assert np.array_equal(dif.device_noise(7, 3, B), z[3])  # deterministic
+    assert not np.allclose(dif.device_noise(8, 3, B), z[3])  # seed matters
+    # the fused loop with the device source == the loop fed the same numbers as an explicit stream
+    cfgs = cfgs_for([1, 10], 3)
+    Bg = cfgs["total_batch_size"]
+    guide = IntersectionVolumeGuide(scenes.random_scene(5, 8), DEV, cfgs, Bg)
+    s, g = scenes.DEFAULT_START, scenes.DEFAULT_GOAL
+    Xd = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=Bg, start=s, goal=g, noise="device", seed=123, t_stop=T - 12)
+    stream = np.zeros((T + 1, Bg, 7, 50))
+    for k in range(13):
+        stream[k] = dif.device_noise(123, k, Bg)
+    Xs = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=Bg, start=s, goal=g, noise=stream, t_stop=T - 12)
+    assert np.array_equal(Xd, Xs)
+    Xfull = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=Bg, start=s, goal=g, noise="device", seed=5)
+    assert np.isfinite(Xfull).all() and np.array_equal(Xfull[:, :, 0], np.broadcast_to(s, (Bg, 7)))
