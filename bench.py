@@ -150,7 +150,7 @@ def main():
 
     # ---- informative: whole-scene wall time when the noise is NOT pre-resident (never `value`) -------------------------
     if world == 1 and rank == 0:
-        def scene(**kw):
+        def scene_time(**kw):
             t1 = time.perf_counter()
             X = dif.denoise_guided(net, guide, N, C, cfgs["guidance_schedule"], batch_size=B, start=start, goal=goal, return_device=True, **kw)
             guide.row_swept_volumes(start, goal, X)
@@ -158,8 +158,8 @@ def main():
             return time.perf_counter() - t1
 
         np.random.seed(0)
-        t_np = scene()                      # reference contract: NumPy draw (91 M normals) + 734 MB upload + loop
-        t_dev = scene(noise="device", seed=1)  # non-parity mode: Philox on the GPU
+        t_np = scene_time()                      # reference contract: NumPy draw (91 M normals) + 734 MB upload + loop
+        t_dev = scene_time(noise="device", seed=1)  # non-parity mode: Philox on the GPU
         out["end_to_end_scene_seconds"] = {
             "noise_resident_in_hbm": dt / args.steps,
             "numpy_stream_drawn_and_uploaded_per_scene": t_np,
