@@ -69,11 +69,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
+    ngpu = torch.cuda.device_count()
+    backend = os.environ.get("EDMP_DIST_BACKEND", "nccl")  # "gloo" lets N ranks share one GPU (single-GPU test boxes)
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ngpu, 1)
+    torch.cuda.set_device(dev_index)
+    dev = f"cuda:{dev_index}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
 
     from edmp_amd import dist as ED
     from edmp_amd import guide_cfg as GC
@@ -118,7 +124,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     value = world * B * T * args.steps / dt
@@ -144,7 +150,8 @@ def main():
                 "global_batch": world * B,
                 "parallelism": f"row-sharded replicas x{world}, end-of-sampling RCCL gather" if world > 1 else "single GPU",
             },
-            "best": {"rank": best["rank"], "row": best["index"], "swept_volume": best["volume"], "geometric_success_proxy": best["success"]},
+            "best": {"rank": best["rank"], "row": best["index"], "swept_volume": best["volume"], "geometric_success_proxy": best["success"],
+                     "note": "random-init denoiser: the proxy (zero t=0 swept AABB volume + joint limits) is expected to be false; reported, never gated"},
             "unet_flops_per_traj_step": {"nominal": nominal, "executed_after_tap_skipping": executed, "survey": SURVEY_FLOPS_PER_TRAJ_STEP},
         }
 

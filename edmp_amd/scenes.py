@@ -60,3 +60,49 @@ class SyntheticDataset:
         lo, hi = joint_limits()
         iks = np.random.RandomState(seed + 2).uniform(lo, hi, (self.n_ik, 7))
         return oc, oc.copy(), np.zeros((0, 10)), oc.shape[0], 0, start, iks
+
+
+# ---- neutral scene files -------------------------------------------------------------------------------------------
+# The reference reads MPiNets problem pickles through geometrout objects (datasets/load_test_dataset.py:76-189): cuboids
+# carry pose quaternions scalar-FIRST and are rolled to scalar-last (:126,:133); cylinders become boxes of extents
+# (r, r, h) (:136-139, quirk Q9).  The pickles/geometrout are not available offline, so the same information is
+# accepted as plain JSON: {"cuboids": [{"center": [x,y,z], "quaternion_wxyz": [w,x,y,z], "dims": [sx,sy,sz]}, ...],
+# "cylinders": [{"center": ..., "quaternion_wxyz": ..., "radius": r, "height": h}, ...], "start": [7], "goals": [[7], ...]}.
+
+
+def problem_to_arrays(problem: dict):
+    """-> (obstacle_config (no,10), start (7,), goals (n,7)) in the fetch_data contract."""
+    rows = []
+    for c in problem.get("cuboids", []):
+        w, x, y, z = c["quaternion_wxyz"]
+        rows.append(np.concatenate([np.asarray(c["center"], float), [x, y, z, w], np.asarray(c["dims"], float)]))
+    for c in problem.get("cylinders", []):
+        w, x, y, z = c["quaternion_wxyz"]
+        rows.append(cylinder_as_box(c["center"], [x, y, z, w], float(c["radius"]), float(c["height"])))
+    if not rows:
+        raise ValueError("scene has no obstacles")
+    oc = np.stack(rows)
+    start = np.asarray(problem["start"], dtype=np.float64)
+    goals = np.atleast_2d(np.asarray(problem["goals"], dtype=np.float64))
+    if oc.shape[1] != 10 or start.shape != (7,) or goals.shape[1] != 7:
+        raise ValueError("malformed problem: need 10-column obstacles, 7-vector start, (n,7) goals")
+    return oc, start, goals
+
+
+def load_problem_file(path: str):
+    import json
+
+    with open(path) as f:
+        return problem_to_arrays(json.load(f))
+
+
+def save_problem_file(path: str, obstacle_config, start, goals) -> None:
+    """inverse of load_problem_file for box obstacles."""
+    import json
+
+    cub = []
+    for o in np.asarray(obstacle_config, float):
+        x, y, z, w = o[3:7]
+        cub.append({"center": o[:3].tolist(), "quaternion_wxyz": [w, x, y, z], "dims": o[7:10].tolist()})
+    with open(path, "w") as f:
+        json.dump({"cuboids": cub, "cylinders": [], "start": np.asarray(start, float).tolist(), "goals": np.atleast_2d(goals).tolist()}, f)

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from edmp_amd import dist as ED
+from edmp_amd import evaluation as EV
 from edmp_amd import guide_cfg as GC
 from edmp_amd.diffusion import Diffusion
 from edmp_amd.guide import IntersectionVolumeGuide
@@ -63,13 +64,18 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True):
                                                    goal=goal_joints, guidance_schedule=guide_cfgs["guidance_schedule"])
             vols, idx = guide.row_swept_volumes(start_joints, goal_joints, trajectories)
             trajectory = trajectories[idx]
-            success = int(ED.geometric_success(float(vols[idx]), trajectory))
+            t_plan = time.time() - t0
+            # success: pybullet execution (lib/environment.py:632-680) is unavailable -> exact oriented-box check along the
+            # interpolated trajectory; the guide's own (conservative, AABB) criterion is reported next to it
+            chk = EV.geometric_success(trajectory, obstacle_config)
+            success = int(chk["success"])
             t_success += success
             i += 1
             results.append(dict(scene_type=scene_type, scene_num=scene_num, best_row=int(idx), swept_volume=float(vols[idx]), success_proxy=success,
-                                planning_time_s=time.time() - t0, trajectory=trajectory))
+                                aabb_volume_zero=bool(ED.geometric_success(float(vols[idx]), trajectory)), first_collision_waypoint=chk["first_collision_waypoint"],
+                                path_length=EV.path_lengths(trajectory), sparc=EV.smoothness(trajectory), planning_time_s=t_plan, trajectory=trajectory))
             if verbose:
-                print(f"Scene {i} ({scene_type}/{scene_num}): planning {time.time() - t0:.2f} s, best row {idx}, swept volume {vols[idx]:.4g}, "
+                print(f"Scene {i} ({scene_type}/{scene_num}): planning {t_plan:.2f} s, best row {idx}, swept volume {vols[idx]:.4g}, "
                       f"geometric success (proxy) {success}   running {t_success}/{i}")
     return results
 
