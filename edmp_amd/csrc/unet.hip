@@ -397,7 +397,11 @@ struct RcbCfg {
         size_t b = 2 * (size_t)STAGE * sizeof(float);
         size_t y = 32 * (size_t)YS * sizeof(float);
         size_t m = b > y ? b : y;
+#ifdef EDMP_EXP_NOPIN
+        return m;
+#else
         return m > 83968 ? m : 83968;  // > 80 KiB: at most one workgroup per CU, so 256 workgroups cover 256 CUs
+#endif
     }
 };
 
