@@ -385,3 +385,83 @@ def test_device_noise_mode(tiny_net):
     assert np.array_equal(Xd, Xs)
     Xfull = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=Bg, start=s, goal=g, noise="device", seed=5)
     assert np.isfinite(Xfull).all() and np.array_equal(Xfull[:, :, 0], np.broadcast_to(s, (Bg, 7)))
+
+
+def test_plain_c_host_through_the_c_abi(golden, tmp_path):
+    """tests/c_abi/c_abi_smoke.c: a C program (gcc, no Python, no torch) binds include/edmp_hip.h, runs 3 guided
+    reverse steps of the reference's own run (golden trace) and picks the best row.  Same numbers as the Python path,
+    and within the north-star tolerance of the reference."""
+    import os
+    import struct
+    import subprocess
+
+    from edmp_amd import franka
+    from edmp_amd import weights as W
+    from edmp_amd.diffusion import Diffusion
+    from edmp_amd.guide import IntersectionVolumeGuide, row_classes
+    from edmp_amd.temporalunet import TemporalUNet
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "c_abi", "c_abi_smoke")
+    assert os.path.exists(exe), "build() compiles tests/c_abi/c_abi_smoke"
+    g = golden("g9_trace_mixed_b12")
+    cfgs = cfgs_for(g["guides"], g["bpg"])
+    B = cfgs["total_batch_size"]
+    sd = W.init_state_dict(5, 7, 32, TINY_DIMS)
+    flat = np.concatenate([np.asarray(sd[k], dtype=np.float32).reshape(-1) for k in W.unet_param_shapes(7, 32, TINY_DIMS)])
+    rc, cclr, cexp = row_classes(cfgs["clearance"], cfgs["expansion"])
+    noise = noise_for(g["seed"], B)
+    t_stop = T - 3
+    blob = struct.pack("<6i", B, g["scene"].shape[0], cclr.shape[0], T, flat.size, t_stop)
+    for arr, dt in ((flat, np.float32), (g["scene"], np.float64), (cclr, np.float64), (cexp, np.float64), (franka.link_half_extents(), np.float32),
+                    (franka.dh_table(), np.float32), (franka.static_frames(), np.float32), (rc, np.int32), (cfgs["guidance_method"], np.float32),
+                    (cfgs["grad_norm"], np.float64), (cfgs["guidance_schedule"], np.float64), (g["start"], np.float64), (g["goal"], np.float64),
+                    (noise, np.float64)):
+        blob += np.ascontiguousarray(arr, dtype=dt).tobytes()
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    fin.write_bytes(blob)
+    r = subprocess.run([exe, str(fin), str(fout)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = fout.read_bytes()
+    n = B * 7 * 50
+    Xc = np.frombuffer(raw[: n * 8], dtype=np.float64).reshape(B, 7, 50)
+    best = struct.unpack("<i", raw[n * 8 : n * 8 + 4])[0]
+    vols = np.frombuffer(raw[n * 8 + 4 :], dtype=np.float32)
+    assert rmse(Xc, g["x_out_253"]) <= 1e-4, rmse(Xc, g["x_out_253"])
+    # identical to the Python mirror (same library underneath)
+    net = TemporalUNet(None, 7, 32, DEV, dims=TINY_DIMS, state_dict=sd, max_batch=B)
+    guide = IntersectionVolumeGuide(g["scene"], DEV, cfgs, B)
+    Xp = Diffusion(T, DEV).denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=g["start"], goal=g["goal"], noise=noise, t_stop=t_stop)
+    assert np.array_equal(Xc, Xp)
+    vp, ip = guide.row_swept_volumes(g["start"], g["goal"], Xp)
+    assert best == ip and np.array_equal(vols, vp)
+
+
+def test_teacher_forced_vs_oracle_at_full_size(oracle):
+    """BASELINE configs[1]/[2] sizes: B = 1024, full 29.9 M-parameter UNet, 6-guide ensemble, 16 obstacles — two
+    teacher-forced reverse steps (one guided) against the CPU oracle, at the north-star tolerance."""
+    from edmp_amd import scenes
+    from edmp_amd import weights as W
+    from edmp_amd.diffusion import Diffusion
+    from edmp_amd.guide import IntersectionVolumeGuide
+    from edmp_amd.guide_cfg import split_rows
+    from edmp_amd.temporalunet import TemporalUNet
+
+    B = 1024
+    sd = W.init_state_dict(1, 7, 32, FULL_DIMS)
+    net = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, state_dict=sd, max_batch=B)
+    guides = [1, 2, 3, 4, 5, 10]
+    cfgs = cfgs_for(guides, 0, rows_per_guide=split_rows(B, len(guides)))
+    scene = scenes.random_scene(11, 16)
+    guide = IntersectionVolumeGuide(scene, DEV, cfgs, B)
+    dif = Diffusion(T, DEV)
+    s, gl = scenes.DEFAULT_START, scenes.DEFAULT_GOAL
+    noise = np.random.RandomState(3).standard_normal((3, B, 7, 50))
+    trace = {}
+    oracle.denoise_guided(oracle.UNetOracle(sd), oracle.GuideOracle(scene, cfgs, B), T, 50, 7, cfgs["guidance_schedule"], B, s, gl, noise=noise, trace=trace, t_stop=T - 2)
+    for t in (255, 254):
+        st = dif.denoise_step(net, guide, trace[t]["x_in"], noise[1 + (T - t)], t, s, gl, cfgs["guidance_schedule"])
+        assert rmse(st["eps"], trace[t]["eps"]) <= 2e-5, (t, rmse(st["eps"], trace[t]["eps"]))
+        if trace[t]["grad"] is not None:
+            assert rmse(st["grad"], trace[t]["grad"]) <= 1e-5, (t, rmse(st["grad"], trace[t]["grad"]))
+        assert rmse(st["x_out"], trace[t]["x_out"]) <= 1e-4, (t, rmse(st["x_out"], trace[t]["x_out"]))
