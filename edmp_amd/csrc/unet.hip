@@ -563,6 +563,27 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
 
     // ---- epilogue: raw tile (+bias) -> LDS, per-sample statistics over the whole group, normalise, Mish, add, store
     float* Y = lds;  // [32][YS]; all MFMA reads of the stages are complete (barrier above)
+    // this thread's epilogue elements are known up front: request their affine parameters and addends from global memory
+    // NOW, so the loads fly under the accumulator spill + statistics phases instead of stalling the final loop
+    const int erow = tid >> 3, epart = tid & 7;
+    const int eb = min(b0 + erow, p.B - 1);
+    float4 g4[NF4], be4[NF4], ad4[NF4];
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+        const int col = 4 * (epart + 8 * i);
+        const int l = col / CG, ch = co0 + col % CG;
+        g4[i] = *reinterpret_cast<const float4*>(p.gamma + ch);
+        be4[i] = *reinterpret_cast<const float4*>(p.beta + ch);
+        ad4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.add_tb) ad4[i] = *reinterpret_cast<const float4*>(p.add_tb + ch);
+        if (p.add_res) {
+            const float4 rr = *reinterpret_cast<const float4*>(p.add_res + ((size_t)eb * L + l) * p.Cout + ch);
+            ad4[i].x += rr.x;
+            ad4[i].y += rr.y;
+            ad4[i].z += rr.z;
+            ad4[i].w += rr.w;
+        }
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int j = wave + 4 * t;
@@ -579,7 +600,7 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
     }
     __syncthreads();
     {
-        const int row = tid >> 3, part = tid & 7;
+        const int row = erow, part = epart;
         const int b = b0 + row;
         float4 v[NF4];
         float sum = 0.f;
@@ -609,32 +630,15 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
                 const int col = 4 * (part + 8 * i);
                 const int l = col / CG, cc = col % CG;
                 const int ch = co0 + cc;
-                const float4 g4 = *reinterpret_cast<const float4*>(p.gamma + ch);
-                const float4 be4 = *reinterpret_cast<const float4*>(p.beta + ch);
                 float4 o;
                 {
-                    const float s0 = rstd * g4.x, s1 = rstd * g4.y, s2 = rstd * g4.z, s3 = rstd * g4.w;
-                    o.x = mish_fast(v[i].x * s0 + (be4.x - s0 * mean));
-                    o.y = mish_fast(v[i].y * s1 + (be4.y - s1 * mean));
-                    o.z = mish_fast(v[i].z * s2 + (be4.z - s2 * mean));
-                    o.w = mish_fast(v[i].w * s3 + (be4.w - s3 * mean));
+                    const float s0 = rstd * g4[i].x, s1 = rstd * g4[i].y, s2 = rstd * g4[i].z, s3 = rstd * g4[i].w;
+                    o.x = mish_fast(v[i].x * s0 + (be4[i].x - s0 * mean)) + ad4[i].x;
+                    o.y = mish_fast(v[i].y * s1 + (be4[i].y - s1 * mean)) + ad4[i].y;
+                    o.z = mish_fast(v[i].z * s2 + (be4[i].z - s2 * mean)) + ad4[i].z;
+                    o.w = mish_fast(v[i].w * s3 + (be4[i].w - s3 * mean)) + ad4[i].w;
                 }
-                const size_t gofs = ((size_t)b * L + l) * p.Cout + ch;
-                if (p.add_tb) {
-                    const float4 tb = *reinterpret_cast<const float4*>(p.add_tb + ch);
-                    o.x += tb.x;
-                    o.y += tb.y;
-                    o.z += tb.z;
-                    o.w += tb.w;
-                }
-                if (p.add_res) {
-                    const float4 rr = *reinterpret_cast<const float4*>(p.add_res + gofs);
-                    o.x += rr.x;
-                    o.y += rr.y;
-                    o.z += rr.z;
-                    o.w += rr.w;
-                }
-                *reinterpret_cast<float4*>(p.dst + gofs) = o;
+                *reinterpret_cast<float4*>(p.dst + ((size_t)b * L + l) * p.Cout + ch) = o;
             }
         }
     }
@@ -811,6 +815,29 @@ __global__ __launch_bounds__(256) void rcb_rows_kernel(RcbP p) {
     const int cg = p.Cout >> 3;       // channels per group (power of two)
     const int cgs = __ffs(cg) - 1;    // log2(cg)
     const int G = CB >> cgs;          // groups in this workgroup
+    // the final pass' affine parameters and addends are requested from global memory now: they land while the
+    // accumulators are spilled to LDS and the statistics are reduced
+    constexpr int NIT = (ROWS * (CB / 4) + 255) / 256;
+    static_assert(NIT <= 8, "epilogue prefetch covers 8 float4 per thread");
+    float4 g4[NIT], be4[NIT], ad4[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int f = min(tid + it * 256, ROWS * (CB / 4) - 1);
+        const int r = f / (CB / 4), c4 = f % (CB / 4);
+        const int ch = co0 + c4 * 4;
+        const int bb = min(b0 + r / L, p.B - 1);
+        g4[it] = *reinterpret_cast<const float4*>(p.gamma + ch);
+        be4[it] = *reinterpret_cast<const float4*>(p.beta + ch);
+        ad4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.add_tb) ad4[it] = *reinterpret_cast<const float4*>(p.add_tb + ch);
+        if (p.add_res) {
+            const float4 rr = *reinterpret_cast<const float4*>(p.add_res + ((size_t)bb * L + r % L) * p.Cout + ch);
+            ad4[it].x += rr.x;
+            ad4[it].y += rr.y;
+            ad4[it].z += rr.z;
+            ad4[it].w += rr.w;
+        }
+    }
     {
         const int cc = lane & 31;
         if (has0) {
@@ -864,41 +891,25 @@ __global__ __launch_bounds__(256) void rcb_rows_kernel(RcbP p) {
         }
     }
     __syncthreads();
-    for (int f = tid; f < ROWS * (CB / 4); f += 256) {
-        const int r = f / (CB / 4), c4 = f % (CB / 4);
-        const int b = r / L, l = r % L;
-        if (b0 + b < p.B) {
-            const int cc = c4 * 4;
-            const int g = cc >> cgs;
-            const float mean = stat[2 * (b * 16 + g)], rstd = stat[2 * (b * 16 + g) + 1];
-            const int ch = co0 + cc;
-            const float4 v = *reinterpret_cast<const float4*>(Y + r * YS + cc);
-            const float4 g4 = *reinterpret_cast<const float4*>(p.gamma + ch);
-            const float4 be4 = *reinterpret_cast<const float4*>(p.beta + ch);
-            float4 o;
-            {
-                const float s0 = rstd * g4.x, s1 = rstd * g4.y, s2 = rstd * g4.z, s3 = rstd * g4.w;
-                o.x = mish_fast(v.x * s0 + (be4.x - s0 * mean));
-                o.y = mish_fast(v.y * s1 + (be4.y - s1 * mean));
-                o.z = mish_fast(v.z * s2 + (be4.z - s2 * mean));
-                o.w = mish_fast(v.w * s3 + (be4.w - s3 * mean));
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int f = tid + it * 256;
+        if (f < ROWS * (CB / 4)) {
+            const int r = f / (CB / 4), c4 = f % (CB / 4);
+            const int b = r / L, l = r % L;
+            if (b0 + b < p.B) {
+                const int cc = c4 * 4;
+                const int g = cc >> cgs;
+                const float mean = stat[2 * (b * 16 + g)], rstd = stat[2 * (b * 16 + g) + 1];
+                const float4 v = *reinterpret_cast<const float4*>(Y + r * YS + cc);
+                float4 o;
+                const float s0 = rstd * g4[it].x, s1 = rstd * g4[it].y, s2 = rstd * g4[it].z, s3 = rstd * g4[it].w;
+                o.x = mish_fast(v.x * s0 + (be4[it].x - s0 * mean)) + ad4[it].x;
+                o.y = mish_fast(v.y * s1 + (be4[it].y - s1 * mean)) + ad4[it].y;
+                o.z = mish_fast(v.z * s2 + (be4[it].z - s2 * mean)) + ad4[it].z;
+                o.w = mish_fast(v.w * s3 + (be4[it].w - s3 * mean)) + ad4[it].w;
+                *reinterpret_cast<float4*>(p.dst + ((size_t)(b0 + b) * L + l) * p.Cout + co0 + cc) = o;
             }
-            const size_t gofs = ((size_t)(b0 + b) * L + l) * p.Cout + ch;
-            if (p.add_tb) {
-                const float4 tb = *reinterpret_cast<const float4*>(p.add_tb + ch);
-                o.x += tb.x;
-                o.y += tb.y;
-                o.z += tb.z;
-                o.w += tb.w;
-            }
-            if (p.add_res) {
-                const float4 rr = *reinterpret_cast<const float4*>(p.add_res + gofs);
-                o.x += rr.x;
-                o.y += rr.y;
-                o.z += rr.z;
-                o.w += rr.w;
-            }
-            *reinterpret_cast<float4*>(p.dst + gofs) = o;
         }
     }
 }
