@@ -198,7 +198,7 @@ __global__ void pack_state_kernel(const double* __restrict__ X, float* __restric
 //   X <- (X - c1 eps)/sqrt(alpha) + beta z                                   (diffusion.py:116-135)
 //   FINISH (steps without guidance): X[:, :, 0] = start, X[:, :, -1] = goal  (diffusion.py:347-349) and the next
 //   step's UNet input [B][N][8] f32 is written, so an unguided reverse step is exactly UNet + this kernel.
-template <bool FINISH, bool RNG>
+template <bool FINISH, bool RNG, int CIN>
 __global__ __launch_bounds__(256) void head_psample_kernel(const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ bias,
                                                            double* __restrict__ X, const double* __restrict__ z, float* __restrict__ eps_out,
                                                            float* __restrict__ xin, const double* __restrict__ sg, int B, int N, int Cin, int C,
@@ -214,16 +214,35 @@ __global__ __launch_bounds__(256) void head_psample_kernel(const float* __restri
     float acc[8];
 #pragma unroll
     for (int co = 0; co < 8; ++co) acc[co] = (co < C) ? bias[co] : 0.0f;
-    for (int c4 = 0; c4 < Cin; c4 += 4) {
-        const float4 hv = *reinterpret_cast<const float4*>(hp + c4);
+    if constexpr (CIN > 0) {  // compile-time width: all input loads are issued back to back, then the FMAs
+        float4 hv[CIN / 4];
 #pragma unroll
-        for (int co = 0; co < 8; ++co) {
-            if (co < C) {
-                const float* wr = w + co * Cin + c4;
-                acc[co] = fmaf(hv.x, wr[0], acc[co]);
-                acc[co] = fmaf(hv.y, wr[1], acc[co]);
-                acc[co] = fmaf(hv.z, wr[2], acc[co]);
-                acc[co] = fmaf(hv.w, wr[3], acc[co]);
+        for (int q = 0; q < CIN / 4; ++q) hv[q] = *reinterpret_cast<const float4*>(hp + 4 * q);
+#pragma unroll
+        for (int q = 0; q < CIN / 4; ++q) {
+#pragma unroll
+            for (int co = 0; co < 8; ++co) {
+                if (co < C) {
+                    const float* wr = w + co * CIN + 4 * q;
+                    acc[co] = fmaf(hv[q].x, wr[0], acc[co]);
+                    acc[co] = fmaf(hv[q].y, wr[1], acc[co]);
+                    acc[co] = fmaf(hv[q].z, wr[2], acc[co]);
+                    acc[co] = fmaf(hv[q].w, wr[3], acc[co]);
+                }
+            }
+        }
+    } else {
+        for (int c4 = 0; c4 < Cin; c4 += 4) {
+            const float4 hv = *reinterpret_cast<const float4*>(hp + c4);
+#pragma unroll
+            for (int co = 0; co < 8; ++co) {
+                if (co < C) {
+                    const float* wr = w + co * Cin + c4;
+                    acc[co] = fmaf(hv.x, wr[0], acc[co]);
+                    acc[co] = fmaf(hv.y, wr[1], acc[co]);
+                    acc[co] = fmaf(hv.z, wr[2], acc[co]);
+                    acc[co] = fmaf(hv.w, wr[3], acc[co]);
+                }
             }
         }
     }
@@ -299,13 +318,20 @@ static int step_a(edmp_ctx* ctx, double* X, const double* z, int B, int t, int z
     const int zr = (zero_row0 && t == 1) ? 1 : 0;
     const int rstep = 1 + (s->T - t);
 #define EDMP_HP_ARGS(xin_ptr) u->h_last, u->head_w, u->head_b, X, z, eps_out, (xin_ptr), s->sg, B, N, u->head_cin, C, s->c1[t - 1], s->sqrt_alpha[t - 1], s->beta[t - 1], zr, seed, rstep
-    if (fused && !g) {
-        if (use_rng) hipLaunchKernelGGL((head_psample_kernel<true, true>), grid_bn, dim3(256), 0, st, EDMP_HP_ARGS(u->x_in));
-        else hipLaunchKernelGGL((head_psample_kernel<true, false>), grid_bn, dim3(256), 0, st, EDMP_HP_ARGS(u->x_in));
-    } else {
-        if (use_rng) hipLaunchKernelGGL((head_psample_kernel<false, true>), grid_bn, dim3(256), 0, st, EDMP_HP_ARGS((float*)nullptr));
-        else hipLaunchKernelGGL((head_psample_kernel<false, false>), grid_bn, dim3(256), 0, st, EDMP_HP_ARGS((float*)nullptr));
+#define EDMP_HP_LAUNCH(FIN, RN, xin_ptr)                                                                                              \
+    {                                                                                                                                  \
+        if (u->head_cin == 32) hipLaunchKernelGGL((head_psample_kernel<FIN, RN, 32>), grid_bn, dim3(256), 0, st, EDMP_HP_ARGS(xin_ptr));      \
+        else if (u->head_cin == 16) hipLaunchKernelGGL((head_psample_kernel<FIN, RN, 16>), grid_bn, dim3(256), 0, st, EDMP_HP_ARGS(xin_ptr)); \
+        else hipLaunchKernelGGL((head_psample_kernel<FIN, RN, 0>), grid_bn, dim3(256), 0, st, EDMP_HP_ARGS(xin_ptr));                        \
     }
+    if (fused && !g) {
+        if (use_rng) EDMP_HP_LAUNCH(true, true, u->x_in)
+        else EDMP_HP_LAUNCH(true, false, u->x_in)
+    } else {
+        if (use_rng) EDMP_HP_LAUNCH(false, true, (float*)nullptr)
+        else EDMP_HP_LAUNCH(false, false, (float*)nullptr)
+    }
+#undef EDMP_HP_LAUNCH
 #undef EDMP_HP_ARGS
     EDMP_HIP_CHECK(hipGetLastError());
     if (xpost_out) EDMP_HIP_CHECK(hipMemcpyAsync(xpost_out, X, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
