@@ -33,8 +33,6 @@ struct Sampler {
     int T = 0;
     std::vector<double> beta, alpha, alpha_bar, c1, sqrt_alpha;  // host tables (f64)
     // scratch for the loop
-    float* x32 = nullptr;   // (B,C,N) f32 UNet input
-    float* eps = nullptr;   // (B,C,N) f32
     double* X = nullptr;    // (B,C,N) f64 loop state
     double* sg = nullptr;   // [14] start|goal f64
     int cap = 0;            // elements
@@ -42,14 +40,9 @@ struct Sampler {
 
 void sampler_destroy(Sampler* s) {
     if (!s) return;
-    for (void* p : {(void*)s->x32, (void*)s->eps, (void*)s->X, (void*)s->sg})
+    for (void* p : {(void*)s->X, (void*)s->sg})
         if (p) (void)hipFree(p);
     delete s;
-}
-
-__global__ void f64_to_f32_kernel(const double* __restrict__ x, float* __restrict__ y, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] = (float)x[i];
 }
 
 // x <- (x - c1 * eps) / sqrt(alpha) + beta * z ; quirk Q3: z of (global) row 0 is zeroed at t == 1
@@ -272,13 +265,8 @@ __global__ __launch_bounds__(256) void head_psample_kernel(const float* __restri
 static int ensure_sampler_scratch(edmp_ctx* ctx, int n) {
     Sampler* s = ctx->sampler;
     if (s->cap >= n) return EDMP_OK;
-    for (void* p : {(void*)s->x32, (void*)s->eps, (void*)s->X})
-        if (p) (void)hipFree(p);
-    s->x32 = nullptr;
-    s->eps = nullptr;
+    if (s->X) (void)hipFree(s->X);
     s->X = nullptr;
-    EDMP_HIP_CHECK(hipMalloc((void**)&s->x32, (size_t)n * sizeof(float)));
-    EDMP_HIP_CHECK(hipMalloc((void**)&s->eps, (size_t)n * sizeof(float)));
     EDMP_HIP_CHECK(hipMalloc((void**)&s->X, (size_t)n * sizeof(double)));
     s->cap = n;
     return EDMP_OK;

@@ -2,14 +2,20 @@
 //
 // Replaces TemporalUNet.forward and the blocks it is built from (reference: diffusion/models/temporalunet.py:47-76,
 // diffusion/models/blocks.py:13-34 Conv1dBlock, :38-92 time embedding, :137-166 ResidualConvolutionBlock,
-// :202-260 Down/Middle/Up samplers).  Design (DESIGN.md §4):
+// :202-260 Down/Middle/Up samplers).  Design (DESIGN.md §4-5):
 //   * activations live in HBM as [B][L][C] fp32 (channels innermost) so that every conv tap of one output position
 //     is a contiguous C-vector per sample; conv weights are repacked once to [tap][Cout][Cin].
-//   * every Conv1d / ConvTranspose1d is an implicit GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32):
-//     M = samples, N = (output position, Cout tile), K = (valid taps) x Cin.  Because a workgroup's N-tile has ONE
-//     output position, taps that fall into the zero padding are skipped entirely (at L=2 only 2 of 5 taps exist).
-//   * GroupNorm(8) + Mish + (time-bias | residual) is one wave per (sample, group), register resident, two-pass
-//     statistics; the whole time-embedding MLP chain depends on t only and is precomputed for t = 1..T at load.
+//   * all matrix work is v_mfma_f32_32x32x2_f32 (exact fp32).  Three kernel families:
+//       rcb_conv_kernel  wide levels (Cout 256/512, L 2/4/7): Conv1d k5 + bias + GroupNorm + Mish + add, one launch;
+//                        workgroup = 32 samples x one GroupNorm group x all L positions.
+//       rcb_rows_kernel  narrow levels (Cout <= 128, L 7..50): the same fusion with GEMM rows = (sample, position);
+//                        workgroup = a few whole samples x 32/64 channels, taps read from one zero-haloed LDS tile.
+//       conv_mfma_kernel everything else (k3 s2, ConvTranspose k4 s2, 1x1 residual convs): implicit GEMM per output
+//                        position; also the whole net with gn_mish_kernel when EDMP_NO_FUSED=1.
+//     Taps that fall into the zero padding are never issued (at L=2 only 2 of 5 taps exist): 122.0 of the 187.3
+//     nominal MFLOP per trajectory-step are executed.
+//   * the whole time-embedding MLP chain depends on t only and is precomputed for t = 1..T at load (time_table_kernel).
+//   * the layer program (which kernel, which buffers) is built once in edmp_unet_load; a forward is ~70 launches.
 #include "common.h"
 
 namespace edmp {
