@@ -51,6 +51,7 @@ SIGNATURES = {
     "edmp_row_swept_volumes_dev": (_i, [_vp, _vp, _i, _i, _pd, _pd, _vp, C.POINTER(_i)]),
     "edmp_sampler_init": (_i, [_vp, _i, _d]),
     "edmp_sampler_read_schedule": (_i, [_vp, _pd, _pd, _pd]),
+    "edmp_sampler_set_condition": (_i, [_vp, _i]),
     "edmp_psample_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "edmp_step_a_dev": (_i, [_vp, _vp, _vp, _i, _i, _pd, _pd, _i, _vp, _vp]),
     "edmp_step_b_dev": (_i, [_vp, _vp, _i, _i, _pd, _pd, _vp]),

@@ -35,6 +35,7 @@ struct Sampler {
     // scratch for the loop
     double* X = nullptr;    // (B,C,N) f64 loop state
     double* sg = nullptr;   // [14] start|goal f64
+    int condition = 1;      // pin X[:, :, 0] / X[:, :, -1] to start / goal (diffusion.py:305-307, 347-349)
     int cap = 0;            // elements
 };
 
@@ -58,7 +59,7 @@ __global__ void psample_kernel(double* __restrict__ X, const float* __restrict__
 // X[:, :, 1:-1] -= sched[:, t-1] * ((1-gn) g + gn g/||g||);  then X[:, :, 0] = start, X[:, :, -1] = goal
 __global__ void update_kernel(double* __restrict__ X, const float* __restrict__ graw, const double* __restrict__ sumsq,
                               const double* __restrict__ grad_norm, const double* __restrict__ sched, int sched_T, int t, int B, int C, int N,
-                              const double* __restrict__ sg, int guided, double* __restrict__ grad_out, float* __restrict__ xin) {
+                              const double* __restrict__ sg, int guided, double* __restrict__ grad_out, float* __restrict__ xin, int cond) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * C * N) return;
     const int l = i % N;
@@ -66,11 +67,15 @@ __global__ void update_kernel(double* __restrict__ X, const float* __restrict__ 
     const int b = i / (N * C);
     double xnew = X[i];
     if (l == 0) {
-        xnew = sg[c];
-        X[i] = xnew;
+        if (cond) {
+            xnew = sg[c];
+            X[i] = xnew;
+        }
     } else if (l == N - 1) {
-        xnew = sg[7 + c];
-        X[i] = xnew;
+        if (cond) {
+            xnew = sg[7 + c];
+            X[i] = xnew;
+        }
     } else if (guided) {
         const int L = N - 2;
         const size_t gi = ((size_t)b * C + c) * L + (l - 1);
@@ -154,7 +159,7 @@ __global__ void rng_normal_kernel(uint64_t seed, int step, double* __restrict__ 
 
 // X_T = N(0, I) with start/goal conditioning, plus the first UNet input              (diffusion.py:303-307)
 __global__ void init_state_rng_kernel(uint64_t seed, double* __restrict__ X, float* __restrict__ xin, const double* __restrict__ sg, int B, int C,
-                                      int N) {
+                                      int N, int cond) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * N) return;
     const int b = i / N, l = i - b * N;
@@ -163,8 +168,8 @@ __global__ void init_state_rng_kernel(uint64_t seed, double* __restrict__ X, flo
     float xo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < C && c < 8; ++c) {
         double x = (double)z[c];
-        if (l == 0) x = sg[c];
-        if (l == N - 1) x = sg[7 + c];
+        if (cond && l == 0) x = sg[c];
+        if (cond && l == N - 1) x = sg[7 + c];
         X[((size_t)b * C + c) * N + l] = x;
         xo[c] = (float)x;
     }
@@ -195,7 +200,7 @@ template <bool FINISH, bool RNG, int CIN>
 __global__ __launch_bounds__(256) void head_psample_kernel(const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ bias,
                                                            double* __restrict__ X, const double* __restrict__ z, float* __restrict__ eps_out,
                                                            float* __restrict__ xin, const double* __restrict__ sg, int B, int N, int Cin, int C,
-                                                           double c1, double sqrt_alpha, double beta, int zero_row0, uint64_t seed, int rng_step) {
+                                                           double c1, double sqrt_alpha, double beta, int zero_row0, uint64_t seed, int rng_step, int cond) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * N) return;
     const int b = i / N, l = i - b * N;
@@ -249,8 +254,8 @@ __global__ __launch_bounds__(256) void head_psample_kernel(const float* __restri
         if (zero_row0 && b == 0) zz = 0.0;
         double x = (X[idx] - c1 * (double)a) / sqrt_alpha + beta * zz;
         if (FINISH) {
-            if (l == 0) x = sg[co];
-            if (l == N - 1) x = sg[7 + co];
+            if (cond && l == 0) x = sg[co];
+            if (cond && l == N - 1) x = sg[7 + co];
             xo[co] = (float)x;
         }
         X[idx] = x;
@@ -305,7 +310,7 @@ static int step_a(edmp_ctx* ctx, double* X, const double* z, int B, int t, int z
     const bool g = guided && guided_step(t);
     const int zr = (zero_row0 && t == 1) ? 1 : 0;
     const int rstep = 1 + (s->T - t);
-#define EDMP_HP_ARGS(xin_ptr) u->h_last, u->head_w, u->head_b, X, z, eps_out, (xin_ptr), s->sg, B, N, u->head_cin, C, s->c1[t - 1], s->sqrt_alpha[t - 1], s->beta[t - 1], zr, seed, rstep
+#define EDMP_HP_ARGS(xin_ptr) u->h_last, u->head_w, u->head_b, X, z, eps_out, (xin_ptr), s->sg, B, N, u->head_cin, C, s->c1[t - 1], s->sqrt_alpha[t - 1], s->beta[t - 1], zr, seed, rstep, s->condition
 #define EDMP_HP_LAUNCH(FIN, RN, xin_ptr)                                                                                              \
     {                                                                                                                                  \
         if (u->head_cin == 32) hipLaunchKernelGGL((head_psample_kernel<FIN, RN, 32>), grid_bn, dim3(256), 0, st, EDMP_HP_ARGS(xin_ptr));      \
@@ -338,8 +343,8 @@ static int step_b(edmp_ctx* ctx, double* X, int B, int t, int guided, double* gr
     if (guided && guided_step(t)) {
         const int n = B * C * N;
         hipLaunchKernelGGL(update_kernel, dim3((n + 255) / 256), dim3(256), 0, st, X, guide_graw(ctx), guide_sumsq(ctx), guide_grad_norm(ctx),
-                           guide_sched(ctx), guide_rows_T(ctx), t, B, C, N, s->sg, 1, grad_out, fused ? u->x_in : nullptr);
-    } else if (!fused) {
+                           guide_sched(ctx), guide_rows_T(ctx), t, B, C, N, s->sg, 1, grad_out, fused ? u->x_in : nullptr, s->condition);
+    } else if (!fused && s->condition) {
         hipLaunchKernelGGL(condition_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, X, B, C, N, s->sg);
     }  // fused + unguided: head_psample_kernel<true> already conditioned X and wrote the next input
     EDMP_HIP_CHECK(hipGetLastError());
@@ -444,6 +449,12 @@ extern "C" int edmp_sampler_init(edmp_ctx* ctx, int T, double variance_thresh) {
     return EDMP_OK;
 }
 
+extern "C" int edmp_sampler_set_condition(edmp_ctx* ctx, int on) {
+    EDMP_REQUIRE(ctx && ctx->sampler, "sampler not initialised");
+    ctx->sampler->condition = on ? 1 : 0;
+    return EDMP_OK;
+}
+
 extern "C" int edmp_sampler_read_schedule(edmp_ctx* ctx, double* beta, double* alpha, double* alpha_bar) {
     EDMP_REQUIRE(ctx && ctx->sampler, "sampler not initialised");
     Sampler* s = ctx->sampler;
@@ -520,10 +531,10 @@ static int denoise_loop(edmp_ctx* ctx, const double* noise_dev, bool use_rng, ui
     hipStream_t st = ctx->stream;
     // X_T with start/goal conditioning                                                  diffusion.py:303-307
     if (use_rng) {
-        hipLaunchKernelGGL(init_state_rng_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, seed, s->X, ctx->unet->x_in, s->sg, B, C, N);
+        hipLaunchKernelGGL(init_state_rng_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, seed, s->X, ctx->unet->x_in, s->sg, B, C, N, s->condition);
     } else {
         EDMP_HIP_CHECK(hipMemcpyAsync(s->X, noise_dev, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(condition_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, s->X, B, C, N, s->sg);
+        if (s->condition) hipLaunchKernelGGL(condition_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, s->X, B, C, N, s->sg);
         hipLaunchKernelGGL(pack_state_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, s->X, ctx->unet->x_in, B, C, N);
     }
     for (int t = T; t > t_stop; --t) {

@@ -72,10 +72,9 @@ class Diffusion:
         """diffusion.py:300-356.  ``noise``: optional pre-drawn (T+1,B,C,N) f64 ndarray / device tensor (default:
         drawn from the global NumPy RNG in the reference's order); ``noise="device"`` draws z on the GPU (Philox,
         ``seed``) — a non-parity mode without the host draw / upload.  Returns (B,C,N) f64 ndarray (a fresh copy)."""
-        if not condition:
-            raise NotImplementedError("the reference driver always conditions on start/goal (infer_serial.py:139)")
         ctx = self.ctx
         self._prepare(model, guide, batch_size, guidance_schedule)
+        _capi.check(ctx.lib.edmp_sampler_set_condition(ctx.h, 1 if condition else 0))
         s = np.ascontiguousarray(np.asarray(start, dtype=np.float64).reshape(-1))
         g = np.ascontiguousarray(np.asarray(goal, dtype=np.float64).reshape(-1))
         out = ctx.empty((batch_size, num_channels, traj_len), torch.float64)
@@ -113,6 +112,7 @@ class Diffusion:
         ctx = self.ctx
         B, Cc, N = X.shape
         self._prepare(model, guide, B, guidance_schedule)
+        _capi.check(ctx.lib.edmp_sampler_set_condition(ctx.h, 1))
         Xd = ctx.to_dev(np.asarray(X, dtype=np.float64), torch.float64).clone()
         zd = ctx.to_dev(np.asarray(z, dtype=np.float64), torch.float64)
         s = np.ascontiguousarray(np.asarray(start, dtype=np.float64).reshape(-1))

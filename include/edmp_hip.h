@@ -106,6 +106,9 @@ int edmp_row_swept_volumes_dev(edmp_ctx* ctx, const double* X_dev, int B, int N,
 /* replaces Diffusion.__init__/schedule_variance (diffusion/diffusion.py:10-20, 37-49) */
 int edmp_sampler_init(edmp_ctx* ctx, int T, double variance_thresh);
 int edmp_sampler_read_schedule(edmp_ctx* ctx, double* beta, double* alpha, double* alpha_bar);
+/* the `condition` argument of denoise_guided / denoise (diffusion.py:305-307, 347-349): pin the first / last waypoint to
+ * start / goal (default on; the reference driver always passes True) */
+int edmp_sampler_set_condition(edmp_ctx* ctx, int on);
 /* replaces p_sample_using_posterior (diffusion.py:116-135) with the noise draw z made explicit.
  * X (B,C,N) f64 updated in place.  zero_row0: apply quirk Q3 (row 0 of z zeroed when t == 1). */
 int edmp_psample_dev(edmp_ctx* ctx, double* X_dev, const float* eps_dev, const double* z_dev, int B, int C, int N,

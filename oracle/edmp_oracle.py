@@ -469,7 +469,7 @@ class UNetOracle:
 
 
 def denoise_guided(
-    model, guide, T, traj_len, num_channels, guidance_schedule, batch_size, start, goal, noise=None, trace=None, t_stop=0
+    model, guide, T, traj_len, num_channels, guidance_schedule, batch_size, start, goal, noise=None, trace=None, t_stop=0, condition=True
 ):
     """Restates Diffusion.denoise_guided.  ``noise`` (T+1, B, C, N) f64: noise[0] is the initial draw
     (diffusion.py:303), noise[1 + (T - t)] the draw of step t (diffusion.py:126); if None it is drawn from the global
@@ -479,8 +479,9 @@ def denoise_guided(
     if noise is None:
         noise = np.random.standard_normal((T + 1, batch_size, num_channels, traj_len))
     X = np.array(noise[0], dtype=np.float64, copy=True)
-    X[:, :, 0] = start[:]
-    X[:, :, -1] = goal[:]
+    if condition:  # diffusion.py:305-307
+        X[:, :, 0] = start[:]
+        X[:, :, -1] = goal[:]
     for t in range(T, t_stop, -1):
         x_in = X.copy() if trace is not None else None
         eps = model(torch.tensor(X, dtype=torch.float32), torch.tensor([t], dtype=torch.float32)).numpy(force=True)
@@ -490,8 +491,9 @@ def denoise_guided(
         if (t % 2) < 1 and t >= 5:
             grad = guide.get_gradient(clip_joints(X[:, :, 1:-1]), start[:], goal[:], t)
             X[:, :, 1:-1] = X[:, :, 1:-1] - guidance_schedule[:, t - 1, np.newaxis, np.newaxis] * grad
-        X[:, :, 0] = start[:]
-        X[:, :, -1] = goal[:]
+        if condition:  # diffusion.py:347-349
+            X[:, :, 0] = start[:]
+            X[:, :, -1] = goal[:]
         if trace is not None:
             trace[t] = dict(x_in=x_in, eps=eps, x_post=x_post, grad=grad, x_out=X.copy())
     return X.copy()

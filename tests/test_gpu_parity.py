@@ -274,6 +274,29 @@ def test_free_running_unguided(oracle, tiny_net):
     assert rmse(X, Xo) <= 1e-4, rmse(X, Xo)
 
 
+def test_condition_false(oracle, tiny_net):
+    """`condition=False` (diffusion.py:305, 347): no start/goal pinning."""
+    from edmp_amd import scenes
+    from edmp_amd.diffusion import Diffusion
+
+    net, sd = tiny_net
+    dif = Diffusion(T, DEV)
+    B = 3
+    noise = noise_for(78, B)
+    s, g = scenes.DEFAULT_START, scenes.DEFAULT_GOAL
+    X = dif.denoise_guided(net, None, 50, 7, None, batch_size=B, start=s, goal=g, condition=False, noise=noise)
+
+    class NoGuide:
+        def get_gradient(self, q, s, g, t):
+            return np.zeros_like(q)
+
+    Xo = oracle.denoise_guided(oracle.UNetOracle(sd), NoGuide(), T, 50, 7, np.zeros((B, T)), B, s, g, noise=noise, condition=False)
+    assert rmse(X, Xo) <= 1e-4, rmse(X, Xo)
+    assert not np.allclose(X[:, :, 0], s)
+    Xc = dif.denoise_guided(net, None, 50, 7, None, batch_size=B, start=s, goal=g, condition=True, noise=noise)
+    assert np.array_equal(Xc[:, :, 0], np.broadcast_to(s, (B, 7)))
+
+
 def test_free_running_guided_envelope(golden, tiny_net):
     """guided loop is chaotic: report RMSE vs the reference's own run, gate only sanity + iv rows."""
     from edmp_amd.diffusion import Diffusion
