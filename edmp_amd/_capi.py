@@ -57,6 +57,7 @@ SIGNATURES = {
     "edmp_step_b_dev": (_i, [_vp, _vp, _i, _i, _pd, _pd, _vp]),
     "edmp_sumsq_ptr_dev": (_vp, [_vp]),
     "edmp_denoise_guided_dev": (_i, [_vp, _vp, _i, _pd, _pd, _i, _i, _i, _vp]),
+    "edmp_denoise_guided_segment_dev": (_i, [_vp, _vp, _i, _pd, _pd, _i, _i, _i, _i, _i, _vp]),
     "edmp_denoise_guided_rng_dev": (_i, [_vp, C.c_uint64, _i, _pd, _pd, _i, _i, _i, _vp]),
     "edmp_rng_normal_dev": (_i, [_vp, C.c_uint64, _i, _i, _i, _i, _vp]),
     "edmp_prof_enable": (_i, [_vp, _i]),

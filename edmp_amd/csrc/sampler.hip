@@ -35,6 +35,7 @@ struct Sampler {
     // scratch for the loop
     double* X = nullptr;    // (B,C,N) f64 loop state
     double* sg = nullptr;   // [14] start|goal f64
+    int run_B = 0;          // batch of the run whose state sits in X (segmented runs)
     int condition = 1;      // pin X[:, :, 0] / X[:, :, -1] to start / goal (diffusion.py:305-307, 347-349)
     int cap = 0;            // elements
 };
@@ -513,50 +514,72 @@ extern "C" int edmp_step_b_dev(edmp_ctx* ctx, double* X_dev, int B, int t, const
 
 extern "C" double* edmp_sumsq_ptr_dev(edmp_ctx* ctx) { return ctx ? guide_sumsq(ctx) : nullptr; }
 
+// The reverse loop for steps t_hi .. t_lo+1.  `init`: build X_T first (noise_dev[0] or the device RNG) and condition it;
+// otherwise continue from the state left in the context by the previous segment.  noise_dev points at the first draw
+// this segment consumes: [X_T draw if init][z of step t_hi][z of step t_hi-1]...  X_out_dev may be NULL (segment in the
+// middle of a chunked run).  A continuation segment performs no host<->device synchronisation, so a caller can draw and
+// upload the next chunk of the NumPy noise stream while this one computes.
 static int denoise_loop(edmp_ctx* ctx, const double* noise_dev, bool use_rng, uint64_t seed, int B, const double* start, const double* goal,
-                        int guided, int t_stop, int zero_row0, double* X_out_dev) {
+                        int guided, int t_hi, int t_lo, bool init, int zero_row0, double* X_out_dev) {
     int rc = check_loop_state(ctx, B, guided != 0);
     if (rc) return rc;
-    EDMP_REQUIRE((noise_dev || use_rng) && start && goal && X_out_dev, "null pointer");
+    EDMP_REQUIRE(noise_dev || use_rng, "null noise pointer");
     Sampler* s = ctx->sampler;
     const int T = s->T;
-    EDMP_REQUIRE(t_stop >= 0 && t_stop < T, "t_stop out of range");
+    EDMP_REQUIRE(t_hi >= 1 && t_hi <= T && t_lo >= 0 && t_lo < t_hi, "step range %d..%d outside 1..%d", t_hi, t_lo + 1, T);
+    EDMP_REQUIRE(!init || t_hi == T, "a run starts at t = T");
     EDMP_HIP_CHECK(hipSetDevice(ctx->device));
     const int C = ctx->unet->desc.input_dim, N = ctx->unet->desc.horizon;
     const size_t n = (size_t)B * C * N;
-    rc = ensure_sampler_scratch(ctx, (int)n);
-    if (rc) return rc;
-    rc = set_startgoal(ctx, start, goal, guided != 0);
-    if (rc) return rc;
     hipStream_t st = ctx->stream;
-    // X_T with start/goal conditioning                                                  diffusion.py:303-307
-    if (use_rng) {
-        hipLaunchKernelGGL(init_state_rng_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, seed, s->X, ctx->unet->x_in, s->sg, B, C, N, s->condition);
+    if (init) {
+        EDMP_REQUIRE(start && goal, "null start/goal");
+        rc = ensure_sampler_scratch(ctx, (int)n);
+        if (rc) return rc;
+        rc = set_startgoal(ctx, start, goal, guided != 0);
+        if (rc) return rc;
+        s->run_B = B;
+        // X_T with start/goal conditioning                                              diffusion.py:303-307
+        if (use_rng) {
+            hipLaunchKernelGGL(init_state_rng_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, seed, s->X, ctx->unet->x_in, s->sg, B, C, N,
+                               s->condition);
+        } else {
+            EDMP_HIP_CHECK(hipMemcpyAsync(s->X, noise_dev, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+            if (s->condition) hipLaunchKernelGGL(condition_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, s->X, B, C, N, s->sg);
+            hipLaunchKernelGGL(pack_state_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, s->X, ctx->unet->x_in, B, C, N);
+            noise_dev += n;
+        }
     } else {
-        EDMP_HIP_CHECK(hipMemcpyAsync(s->X, noise_dev, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-        if (s->condition) hipLaunchKernelGGL(condition_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, s->X, B, C, N, s->sg);
-        hipLaunchKernelGGL(pack_state_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, s->X, ctx->unet->x_in, B, C, N);
+        EDMP_REQUIRE(s->X && s->run_B == B, "no run in progress for batch %d (call with init first)", B);
     }
-    for (int t = T; t > t_stop; --t) {
-        const double* z = use_rng ? nullptr : noise_dev + (size_t)(1 + (T - t)) * n;
+    for (int t = t_hi; t > t_lo; --t) {
+        const double* z = use_rng ? nullptr : noise_dev + (size_t)(t_hi - t) * n;
         rc = step_a(ctx, s->X, z, B, t, zero_row0, guided, nullptr, nullptr, true, use_rng, seed);
         if (rc) return rc;
         rc = step_b(ctx, s->X, B, t, guided, nullptr, true);
         if (rc) return rc;
     }
-    EDMP_HIP_CHECK(hipMemcpyAsync(X_out_dev, s->X, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (X_out_dev) EDMP_HIP_CHECK(hipMemcpyAsync(X_out_dev, s->X, n * sizeof(double), hipMemcpyDeviceToDevice, st));
     return EDMP_OK;
 }
 
 extern "C" int edmp_denoise_guided_dev(edmp_ctx* ctx, const double* noise_dev, int B, const double* start, const double* goal, int guided,
                                        int t_stop, int zero_row0, double* X_out_dev) {
-    EDMP_REQUIRE(noise_dev, "edmp_denoise_guided_dev: noise_dev is NULL (use edmp_denoise_guided_rng_dev for the device noise source)");
-    return denoise_loop(ctx, noise_dev, false, 0, B, start, goal, guided, t_stop, zero_row0, X_out_dev);
+    EDMP_REQUIRE(noise_dev && X_out_dev, "edmp_denoise_guided_dev: null pointer (use edmp_denoise_guided_rng_dev for the device noise source)");
+    EDMP_REQUIRE(ctx && ctx->sampler, "sampler not initialised");
+    return denoise_loop(ctx, noise_dev, false, 0, B, start, goal, guided, ctx->sampler->T, t_stop, true, zero_row0, X_out_dev);
 }
 
 extern "C" int edmp_denoise_guided_rng_dev(edmp_ctx* ctx, uint64_t seed, int B, const double* start, const double* goal, int guided, int t_stop,
                                            int zero_row0, double* X_out_dev) {
-    return denoise_loop(ctx, nullptr, true, seed, B, start, goal, guided, t_stop, zero_row0, X_out_dev);
+    EDMP_REQUIRE(ctx && ctx->sampler && X_out_dev, "sampler not initialised / null output");
+    return denoise_loop(ctx, nullptr, true, seed, B, start, goal, guided, ctx->sampler->T, t_stop, true, zero_row0, X_out_dev);
+}
+
+extern "C" int edmp_denoise_guided_segment_dev(edmp_ctx* ctx, const double* noise_dev, int B, const double* start, const double* goal, int guided,
+                                               int t_hi, int t_lo, int init, int zero_row0, double* X_out_dev) {
+    EDMP_REQUIRE(ctx && ctx->sampler && noise_dev, "edmp_denoise_guided_segment_dev: bad arguments");
+    return denoise_loop(ctx, noise_dev, false, 0, B, start, goal, guided, t_hi, t_lo, init != 0, zero_row0, X_out_dev);
 }
 
 extern "C" int edmp_rng_normal_dev(edmp_ctx* ctx, uint64_t seed, int step_index, int B, int C, int N, double* out_dev) {

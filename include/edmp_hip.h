@@ -131,6 +131,14 @@ double* edmp_sumsq_ptr_dev(edmp_ctx* ctx);
 int edmp_denoise_guided_dev(edmp_ctx* ctx, const double* noise_dev, int B, const double* start, const double* goal,
                             int guided, int t_stop, int zero_row0, double* X_out_dev);
 
+/* The same loop in segments (steps t_hi .. t_lo+1), for callers that produce the noise stream while the GPU works:
+ * init != 0 starts a run at t_hi = T (noise_dev[0] is the X_T draw, then one (B,C,N) draw per step); init == 0 continues
+ * from the state kept in the context (noise_dev[0] is the draw of step t_hi) and performs no host synchronisation.
+ * X_out_dev may be NULL except for the last segment.  Used by Diffusion.denoise_guided to overlap NumPy's RandomState
+ * (the reference's noise contract, ~0.85 s per 1024-row scene on the host) with the denoising itself. */
+int edmp_denoise_guided_segment_dev(edmp_ctx* ctx, const double* noise_dev, int B, const double* start, const double* goal,
+                                    int guided, int t_hi, int t_lo, int init, int zero_row0, double* X_out_dev);
+
 /* Device noise source — explicitly NOT the reference's NumPy RandomState stream (that contract is served by
  * edmp_denoise_guided_dev): Philox4x32-10 counter RNG + Box-Muller inside the sampler kernels, no noise tensor, no
  * host draw, no upload.  Same loop otherwise (replaces diffusion.py:300-356 with z ~ N(0, I) drawn on the GPU).

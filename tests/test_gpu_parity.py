@@ -274,6 +274,32 @@ def test_free_running_unguided(oracle, tiny_net):
     assert rmse(X, Xo) <= 1e-4, rmse(X, Xo)
 
 
+def test_chunked_numpy_stream_equals_resident_stream(golden, tiny_net):
+    """noise=None draws NumPy's global stream in chunks while the GPU works (segmented loop): same numbers, same result
+    as uploading the whole (T+1,B,7,50) stream first — for chunk sizes that do and do not divide T."""
+    from edmp_amd.diffusion import Diffusion
+    from edmp_amd.guide import IntersectionVolumeGuide
+
+    net, _ = tiny_net
+    g = golden("g9_trace_mixed_b12")
+    cfgs = cfgs_for(g["guides"], g["bpg"])
+    B = cfgs["total_batch_size"]
+    guide = IntersectionVolumeGuide(g["scene"], DEV, cfgs, B)
+    dif = Diffusion(T, DEV)
+    Xr = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=g["start"], goal=g["goal"], noise=noise_for(31, B))
+    for chunk in (16, 7, 255, 1000):
+        np.random.seed(31)
+        Xc = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=g["start"], goal=g["goal"], chunk_steps=chunk)
+        assert np.array_equal(Xc, Xr), chunk
+    # the RNG is left exactly where the reference leaves it: (T + 1) * B * 7 * 50 normals consumed
+    np.random.seed(31)
+    dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=g["start"], goal=g["goal"])
+    after = np.random.standard_normal(3)
+    np.random.seed(31)
+    np.random.standard_normal((T + 1, B, 7, 50))
+    assert np.array_equal(after, np.random.standard_normal(3))
+
+
 def test_condition_false(oracle, tiny_net):
     """`condition=False` (diffusion.py:305, 347): no start/goal pinning."""
     from edmp_amd import scenes
