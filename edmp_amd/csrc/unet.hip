@@ -150,12 +150,33 @@ struct RcbP {
     int B;
 };
 
-enum OpKind { OP_CONV = 0, OP_GN = 1, OP_RCB = 2 };
+struct BlkP {
+    const float* src1;
+    const float* src2;
+    int C1, C2;
+    const float* W1;  // [5][C][Cin]
+    const float* b1;
+    const float* g1;
+    const float* be1;
+    const float* tb;  // [C] time bias of step t
+    const float* W2;  // [5][C][C]
+    const float* b2;
+    const float* g2;
+    const float* be2;
+    const float* Wr;  // [C][Cin] residual 1x1 conv (RES) or nullptr (identity: src1 is the residual)
+    const float* br;
+    float* dst;  // [B][L][C]
+    int B;
+};
+
+enum OpKind { OP_CONV = 0, OP_GN = 1, OP_RCB = 2, OP_BLK = 3 };
 struct Op {
     OpKind kind;
     ConvP cv;
     GnP gn;
     RcbP rc;
+    BlkP bk;      // OP_BLK: a whole residual block
+    int bk_variant;
     int rc_L;     // OP_RCB: positions
     int rc_rows;  // OP_RCB: 0 = rcb_conv_kernel (wide levels), else rcb_rows_kernel variant
     int tb_off;   // GN: offset into the time-bias row, -1 if none
@@ -920,6 +941,363 @@ __global__ __launch_bounds__(256) void rcb_rows_kernel(RcbP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// A WHOLE ResidualConvolutionBlock (blocks.py:137-166) in one launch, for the narrowest levels (C = 32 or 64 output
+// channels): a workgroup owns SB whole samples x ALL C channels, so after conv1 + GroupNorm + Mish + time-bias the
+// hidden activation h of its samples is complete in LDS and conv2 reads its tap-shifted operands straight from that
+// tile; the residual (identity, or the 1x1 conv of the block input accumulated next to conv1) is added in registers.
+// These levels are launch-latency-bound (a fused conv of 32 channels is ~10 us of which ~2 are MFMAs): halving the
+// number of launches is worth more than any in-kernel tuning.  grid = (1, B/SB).
+
+template <int C, int L, int SB, int KC1, bool RES>
+struct BlkCfg {
+    static constexpr int LDK1 = KC1 + 4, LDK2 = 36, HS = C + 4, YS = C + 4;
+    static constexpr int ROWS = SB * L, MT = (ROWS + 31) / 32, NT = C / 32, NTILE = MT * NT, TPW = (NTILE + 3) / 4;
+    static constexpr int XR = SB * (L + 4);
+    static constexpr int NSLAB = RES ? 6 : 5;
+    static constexpr int A1_FL = XR * LDK1, B1_FL = NSLAB * C * LDK1, STAGE1 = A1_FL + B1_FL;
+    static constexpr int B2_FL = 5 * C * LDK2;  // one K chunk of conv2's weights
+    static constexpr int H_FL = XR * HS;
+    static constexpr int Y_FL = MT * 32 * YS;
+    static constexpr int STAT_FL = 2 * SB * 16;
+    // conv1 needs a second stage only if it has more than one K chunk (an identity-residual block has Cin = C);
+    // conv2 has C/32 chunks.  Keeping LDS small lets two or three of these latency-bound workgroups share a CU.
+    static constexpr int NST1 = (!RES && C == KC1) ? 1 : 2;
+    static constexpr int NST2 = C / 32;
+    static constexpr int W1_ = NST1 * STAGE1, W2_ = Y_FL + STAT_FL, W3_ = NST2 * B2_FL;
+    static constexpr int WORK_FL = (W1_ > W2_ ? W1_ : W2_) > W3_ ? (W1_ > W2_ ? W1_ : W2_) : W3_;
+    static constexpr size_t lds_bytes() { return ((size_t)H_FL + WORK_FL) * sizeof(float); }
+    static constexpr int A1_F4 = ROWS * (KC1 / 4), B1_F4 = NSLAB * C * (KC1 / 4), B2_F4 = 5 * C * 8;
+    static constexpr int NA1 = (A1_F4 + 255) / 256, NB1 = (B1_F4 + 255) / 256, NB2 = (B2_F4 + 255) / 256;
+};
+
+template <int C, int L, int SB, int KC1, bool RES>
+__global__ __launch_bounds__(256) void rcb_block_kernel(BlkP p) {
+    using Cf = BlkCfg<C, L, SB, KC1, RES>;
+    constexpr int LDK1 = Cf::LDK1, LDK2 = Cf::LDK2, HS = Cf::HS, YS = Cf::YS, ROWS = Cf::ROWS, NT = Cf::NT, NTILE = Cf::NTILE, TPW = Cf::TPW;
+    constexpr int A1_FL = Cf::A1_FL, STAGE1 = Cf::STAGE1, B2_FL = Cf::B2_FL, H_FL = Cf::H_FL, Y_FL = Cf::Y_FL;
+    constexpr int A1_F4 = Cf::A1_F4, B1_F4 = Cf::B1_F4, B2_F4 = Cf::B2_F4, NA1 = Cf::NA1, NB1 = Cf::NB1, NB2 = Cf::NB2, F4R1 = KC1 / 4;
+    static_assert(NA1 <= 4 && NB1 <= 12 && NB2 <= 12 && TPW <= 2, "staging macros: NA1 <= 4, NB <= 12, two tiles per wave");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* H = lds;            // [SB][L+4][HS]: hidden activation with zero halos, lives across both phases
+    float* work = lds + H_FL;  // phase 1 stages | Y | phase 2 weight stages
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int b0 = blockIdx.y * SB;
+    const int Cin = p.C1 + p.C2;
+    const int ch1 = p.C1 / KC1, ch2 = p.C2 / KC1;
+    const int nK1 = ch1 + ch2;
+
+    for (int i = tid; i < H_FL / 4; i += 256) *reinterpret_cast<float4*>(H + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < A1_FL / 4; i += 256) {
+        *reinterpret_cast<float4*>(work + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (Cf::NST1 == 2) *reinterpret_cast<float4*>(work + STAGE1 + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+#define EDMP_REP4(M) M(0) M(1) M(2) M(3)
+#define EDMP_REP12(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
+#define EDMP_DECL_XA(i)                                                                                         \
+    const int fa##i = tid + i * 256;                                                                            \
+    const bool pa##i = (i < NA1) && (fa##i < A1_F4);                                                            \
+    const int rr##i = min(fa##i / F4R1, ROWS - 1);                                                              \
+    const int ga1_##i = (min(b0 + rr##i / L, p.B - 1) * L + rr##i % L) * p.C1 + (fa##i % F4R1) * 4;             \
+    const int ga2_##i = (min(b0 + rr##i / L, p.B - 1) * L + rr##i % L) * p.C2 + (fa##i % F4R1) * 4;             \
+    const int la##i = ((rr##i / L) * (L + 4) + rr##i % L + 2) * LDK1 + (fa##i % F4R1) * 4;                      \
+    float4 xa##i = make_float4(0.f, 0.f, 0.f, 0.f);
+// weight slabs 0..4 = conv1 taps ([tap][C][Cin]), slab 5 = the residual 1x1 conv ([C][Cin])
+#define EDMP_DECL_XB(i)                                                                                         \
+    const int fb##i = min(tid + i * 256, B1_F4 - 1);                                                            \
+    const bool pb##i = (i < NB1) && (tid + i * 256 < B1_F4);                                                    \
+    const int sl##i = fb##i / (C * F4R1), co##i = (fb##i % (C * F4R1)) / F4R1, cq##i = (fb##i % F4R1) * 4;      \
+    const float* gb##i = (sl##i < 5 ? p.W1 + ((size_t)sl##i * C + co##i) * Cin : p.Wr + (size_t)co##i * Cin) + cq##i; \
+    const int lb##i = A1_FL + (sl##i * C + co##i) * LDK1 + cq##i;                                               \
+    float4 xb##i = make_float4(0.f, 0.f, 0.f, 0.f);
+    EDMP_REP4(EDMP_DECL_XA)
+    EDMP_REP12(EDMP_DECL_XB)
+#define EDMP_LD_XA(i) \
+    if (pa##i) xa##i = *reinterpret_cast<const float4*>(src_ + (first_ ? ga1_##i : ga2_##i) + ci0_);
+#define EDMP_LD_XB(i) \
+    if (pb##i) xb##i = *reinterpret_cast<const float4*>(gb##i + wofs_);
+#define EDMP_ST_XA(i) \
+    if (pa##i) *reinterpret_cast<float4*>(sn_ + la##i) = xa##i;
+#define EDMP_ST_XB(i) \
+    if (pb##i) *reinterpret_cast<float4*>(sn_ + lb##i) = xb##i;
+#define EDMP_BLK_FETCH1(nc)                                          \
+    {                                                                \
+        const bool first_ = (nc) < ch1;                              \
+        const float* src_ = first_ ? p.src1 : p.src2;                \
+        const int ci0_ = (first_ ? (nc) : (nc)-ch1) * KC1;           \
+        const int wofs_ = (first_ ? 0 : p.C1) + ci0_;                \
+        EDMP_REP4(EDMP_LD_XA) EDMP_REP12(EDMP_LD_XB)                 \
+    }
+#define EDMP_BLK_COMMIT1(stage_ptr)                    \
+    {                                                  \
+        float* sn_ = (stage_ptr);                      \
+        EDMP_REP4(EDMP_ST_XA) EDMP_REP12(EDMP_ST_XB)   \
+    }
+
+    f32x16 acc0, acc1, rac0, rac1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        acc0[i] = 0.0f;
+        acc1[i] = 0.0f;
+        rac0[i] = 0.0f;
+        rac1[i] = 0.0f;
+    }
+    const int j0 = wave, j1 = wave + 4;
+    const bool has0 = j0 < NTILE, has1 = (TPW > 1) && (j1 < NTILE);
+    const int fr = 4 * (lane >> 5);
+    const int r0 = min((j0 / NT) * 32 + (lane & 31), ROWS - 1);
+    const int r1 = min((j1 / NT) * 32 + (lane & 31), ROWS - 1);
+    const int xr0 = (r0 / L) * (L + 4) + r0 % L, xr1 = (r1 / L) * (L + 4) + r1 % L;  // + tap
+    const int bcol0 = (j0 % NT) * 32 + (lane & 31), bcol1 = (j1 % NT) * 32 + (lane & 31);
+
+    __syncthreads();
+    EDMP_BLK_FETCH1(0)
+    EDMP_BLK_COMMIT1(work)
+    __syncthreads();
+
+// conv1 taps (+ the residual slab at the centre tap) of one K chunk for one 32x32 tile
+#define EDMP_BLK_TILE1(st, accv, racv, xr, bcol)                                                      \
+    _Pragma("unroll") for (int k = 0; k < Cf::NSLAB; ++k) {                                            \
+        const float* a_s = (st) + ((xr) + (k < 5 ? k : 2)) * LDK1 + fr;                                \
+        const float* b_s = (st) + A1_FL + (k * C + (bcol)) * LDK1 + fr;                                \
+        _Pragma("unroll") for (int q = 0; q < KC1 / 8; ++q) {                                          \
+            const float4 a4 = *reinterpret_cast<const float4*>(a_s + 8 * q);                           \
+            const float4 b4 = *reinterpret_cast<const float4*>(b_s + 8 * q);                           \
+            if (k < 5) {                                                                               \
+                accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, accv, 0, 0, 0);                \
+                accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, accv, 0, 0, 0);                \
+                accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, accv, 0, 0, 0);                \
+                accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, accv, 0, 0, 0);                \
+            } else {                                                                                   \
+                racv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, racv, 0, 0, 0);                \
+                racv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, racv, 0, 0, 0);                \
+                racv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, racv, 0, 0, 0);                \
+                racv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, racv, 0, 0, 0);                \
+            }                                                                                          \
+        }                                                                                              \
+    }
+#define EDMP_BLK_COMPUTE1(st)                                          \
+    if (has0) { EDMP_BLK_TILE1(st, acc0, rac0, xr0, bcol0) }           \
+    if (has1) { EDMP_BLK_TILE1(st, acc1, rac1, xr1, bcol1) }
+
+    for (int kk = 0; kk < nK1 - 1; ++kk) {
+        const int cur = kk & 1;
+        EDMP_BLK_FETCH1(kk + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        EDMP_BLK_COMPUTE1(work + cur * STAGE1)
+        __builtin_amdgcn_sched_barrier(0);
+        EDMP_BLK_COMMIT1(work + (cur ^ 1) * STAGE1)
+        __syncthreads();
+    }
+    EDMP_BLK_COMPUTE1(work + ((nK1 - 1) & 1) * STAGE1)
+#undef EDMP_BLK_COMPUTE1
+#undef EDMP_BLK_TILE1
+#undef EDMP_BLK_FETCH1
+#undef EDMP_BLK_COMMIT1
+#undef EDMP_LD_XA
+#undef EDMP_LD_XB
+#undef EDMP_ST_XA
+#undef EDMP_ST_XB
+#undef EDMP_DECL_XA
+#undef EDMP_DECL_XB
+
+    // conv2's first weight chunk is requested now; it lands under epilogue 1
+#define EDMP_DECL_W2(i)                                                                                  \
+    const int f2##i = min(tid + i * 256, B2_F4 - 1);                                                     \
+    const bool p2##i = (i < NB2) && (tid + i * 256 < B2_F4);                                             \
+    const float* g2p##i = p.W2 + ((size_t)(f2##i / (C * 8)) * C + (f2##i % (C * 8)) / 8) * C + (f2##i % 8) * 4; \
+    const int l2##i = ((f2##i / (C * 8)) * C + (f2##i % (C * 8)) / 8) * LDK2 + (f2##i % 8) * 4;           \
+    float4 w2##i = make_float4(0.f, 0.f, 0.f, 0.f);
+    EDMP_REP12(EDMP_DECL_W2)
+#define EDMP_LD_W2(i) \
+    if (p2##i) w2##i = *reinterpret_cast<const float4*>(g2p##i + ci2_);
+#define EDMP_ST_W2(i) \
+    if (p2##i) *reinterpret_cast<float4*>(sn_ + l2##i) = w2##i;
+#define EDMP_BLK_FETCH2(nc)       \
+    {                             \
+        const int ci2_ = (nc)*32; \
+        EDMP_REP12(EDMP_LD_W2)    \
+    }
+#define EDMP_BLK_COMMIT2(stage_ptr)  \
+    {                                \
+        float* sn_ = (stage_ptr);    \
+        EDMP_REP12(EDMP_ST_W2)       \
+    }
+    EDMP_BLK_FETCH2(0)
+    __syncthreads();  // every wave is done with the conv1 stages
+
+    // ---- epilogue 1: Y = conv1 + b1 -> statistics -> h = Mish(GN(Y)) + tb, written into the haloed H tile
+    float* Y = work;
+    float* stat = work + Y_FL;
+    constexpr int CG = C / 8;                      // channels per group
+    constexpr int CGS = (CG == 4) ? 2 : 3;         // log2
+    constexpr int G = 8;
+    {
+        const int cc = lane & 31;
+        if (has0) {
+            const int mt = j0 / NT, nt = j0 % NT;
+            const float bias = p.b1[nt * 32 + cc];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Y[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * YS + nt * 32 + cc] = acc0[r] + bias;
+        }
+        if (has1) {
+            const int mt = j1 / NT, nt = j1 % NT;
+            const float bias = p.b1[nt * 32 + cc];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Y[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * YS + nt * 32 + cc] = acc1[r] + bias;
+        }
+    }
+    __syncthreads();
+// per (sample, group) mean / rstd of the Y tile, 16 lanes per unit, two-pass
+#define EDMP_BLK_STATS()                                                                   \
+    {                                                                                      \
+        const int l16 = tid & 15;                                                          \
+        constexpr int n_ = L * CG;                                                         \
+        constexpr float inv_n = 1.0f / (float)n_;                                          \
+        for (int u = tid >> 4; u < SB * G; u += 16) {                                      \
+            const int b = u / G, g = u - b * G;                                            \
+            const float* yb = Y + (b * L) * YS + g * CG;                                   \
+            float sum = 0.f;                                                               \
+            for (int e = l16; e < n_; e += 16) sum += yb[(e >> CGS) * YS + (e & (CG - 1))]; \
+            sum += __shfl_xor(sum, 1, 64);                                                 \
+            sum += __shfl_xor(sum, 2, 64);                                                 \
+            sum += __shfl_xor(sum, 4, 64);                                                 \
+            sum += __shfl_xor(sum, 8, 64);                                                 \
+            const float mean = sum * inv_n;                                                \
+            float sq = 0.f;                                                                \
+            for (int e = l16; e < n_; e += 16) {                                           \
+                const float d = yb[(e >> CGS) * YS + (e & (CG - 1))] - mean;               \
+                sq += d * d;                                                               \
+            }                                                                              \
+            sq += __shfl_xor(sq, 1, 64);                                                   \
+            sq += __shfl_xor(sq, 2, 64);                                                   \
+            sq += __shfl_xor(sq, 4, 64);                                                   \
+            sq += __shfl_xor(sq, 8, 64);                                                   \
+            if (l16 == 0) {                                                                \
+                stat[2 * (b * 16 + g)] = mean;                                             \
+                stat[2 * (b * 16 + g) + 1] = 1.0f / sqrtf(sq * inv_n + 1e-5f);             \
+            }                                                                              \
+        }                                                                                  \
+    }
+    EDMP_BLK_STATS()
+    __syncthreads();
+    for (int f = tid; f < ROWS * (C / 4); f += 256) {
+        const int r = f / (C / 4), cc = (f % (C / 4)) * 4;
+        const int b = r / L, l = r % L;
+        const int g = cc >> CGS;
+        const float mean = stat[2 * (b * 16 + g)], rstd = stat[2 * (b * 16 + g) + 1];
+        const float4 v = *reinterpret_cast<const float4*>(Y + r * YS + cc);
+        const float4 g4 = *reinterpret_cast<const float4*>(p.g1 + cc);
+        const float4 be4 = *reinterpret_cast<const float4*>(p.be1 + cc);
+        const float4 tb4 = *reinterpret_cast<const float4*>(p.tb + cc);
+        float4 o;
+        const float s0 = rstd * g4.x, s1 = rstd * g4.y, s2 = rstd * g4.z, s3 = rstd * g4.w;
+        o.x = mish_fast(v.x * s0 + (be4.x - s0 * mean)) + tb4.x;
+        o.y = mish_fast(v.y * s1 + (be4.y - s1 * mean)) + tb4.y;
+        o.z = mish_fast(v.z * s2 + (be4.z - s2 * mean)) + tb4.z;
+        o.w = mish_fast(v.w * s3 + (be4.w - s3 * mean)) + tb4.w;
+        *reinterpret_cast<float4*>(H + (b * (L + 4) + l + 2) * HS + cc) = o;
+    }
+    __syncthreads();  // H complete, Y dead
+
+    // ---- phase 2: conv2 over the C channels of H (A operand straight from the H tile), weights streamed per 32-channel chunk
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        acc0[i] = 0.0f;
+        acc1[i] = 0.0f;
+    }
+    EDMP_BLK_COMMIT2(work)
+    __syncthreads();
+    constexpr int nK2 = C / 32;
+#define EDMP_BLK_TILE2(st, accv, xr, bcol, ci0)                                                        \
+    _Pragma("unroll") for (int k = 0; k < 5; ++k) {                                                    \
+        const float* a_s = H + ((xr) + k) * HS + (ci0) + fr;                                           \
+        const float* b_s = (st) + (k * C + (bcol)) * LDK2 + fr;                                        \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                \
+            const float4 a4 = *reinterpret_cast<const float4*>(a_s + 8 * q);                           \
+            const float4 b4 = *reinterpret_cast<const float4*>(b_s + 8 * q);                           \
+            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, accv, 0, 0, 0);                    \
+            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, accv, 0, 0, 0);                    \
+            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, accv, 0, 0, 0);                    \
+            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, accv, 0, 0, 0);                    \
+        }                                                                                              \
+    }
+#pragma unroll
+    for (int kk = 0; kk < nK2; ++kk) {
+        if (kk + 1 < nK2) EDMP_BLK_FETCH2(kk + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        const float* st2 = work + (kk & 1) * B2_FL;
+        if (has0) { EDMP_BLK_TILE2(st2, acc0, xr0, bcol0, kk * 32) }
+        if (has1) { EDMP_BLK_TILE2(st2, acc1, xr1, bcol1, kk * 32) }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk + 1 < nK2) EDMP_BLK_COMMIT2(work + ((kk + 1) & 1) * B2_FL)
+        __syncthreads();
+    }
+#undef EDMP_BLK_TILE2
+#undef EDMP_BLK_FETCH2
+#undef EDMP_BLK_COMMIT2
+#undef EDMP_LD_W2
+#undef EDMP_ST_W2
+#undef EDMP_DECL_W2
+#undef EDMP_REP4
+#undef EDMP_REP12
+
+    // ---- epilogue 2: statistics of conv2 + b2 via LDS, then out = Mish(GN(.)) + residual applied in the accumulator layout
+    {
+        const int cc = lane & 31;
+        if (has0) {
+            const int mt = j0 / NT, nt = j0 % NT;
+            const float bias = p.b2[nt * 32 + cc];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc0[r] += bias;
+                Y[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * YS + nt * 32 + cc] = acc0[r];
+            }
+        }
+        if (has1) {
+            const int mt = j1 / NT, nt = j1 % NT;
+            const float bias = p.b2[nt * 32 + cc];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc1[r] += bias;
+                Y[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * YS + nt * 32 + cc] = acc1[r];
+            }
+        }
+    }
+    __syncthreads();
+    EDMP_BLK_STATS()
+#undef EDMP_BLK_STATS
+    __syncthreads();
+#define EDMP_BLK_OUT(accv, racv, jj)                                                                         \
+    {                                                                                                        \
+        const int mt = (jj) / NT, nt = (jj) % NT;                                                            \
+        const int ch = nt * 32 + (lane & 31);                                                                \
+        const int g = ch >> CGS;                                                                             \
+        const float gam = p.g2[ch], bet = p.be2[ch];                                                         \
+        const float rbias = RES ? p.br[ch] : 0.0f;                                                           \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                     \
+            const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);                              \
+            if (row < ROWS) {                                                                                \
+                const int b = row / L, l = row % L;                                                          \
+                if (b0 + b < p.B) {                                                                          \
+                    const float mean = stat[2 * (b * 16 + g)], rstd = stat[2 * (b * 16 + g) + 1];            \
+                    const float sc = rstd * gam;                                                             \
+                    const size_t go = ((size_t)(b0 + b) * L + l) * C + ch;                                   \
+                    const float res = RES ? (racv[r] + rbias) : p.src1[go];                                  \
+                    p.dst[go] = mish_fast(accv[r] * sc + (bet - sc * mean)) + res;                           \
+                }                                                                                            \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+    if (has0) EDMP_BLK_OUT(acc0, rac0, j0)
+    if (has1) EDMP_BLK_OUT(acc1, rac1, j1)
+#undef EDMP_BLK_OUT
+}
+
 // GroupNorm(8 groups, eps 1e-5, biased variance) -> Mish -> (+ time bias[c] | + residual[b,l,c]) in place.
 // One wave per (sample, group); the (C/8) x L elements of the group stay in registers between the passes.
 template <int EPL>  // elements per lane
@@ -1124,6 +1502,47 @@ static int launch_rows(const RcbP& p, int variant, hipStream_t s) {
     set_error("no narrow fused kernel variant %d", variant);
     return EDMP_ERR_STATE;
 }
+template <int C, int L, int SB, int KC1, bool RES>
+static int launch_blk_t(const BlkP& p, hipStream_t s) {
+    static bool attr_set = false;
+    constexpr size_t bytes = BlkCfg<C, L, SB, KC1, RES>::lds_bytes();
+    static_assert(bytes <= 160 * 1024, "whole-block kernel exceeds the 160 KiB LDS of a CU");
+    if (!attr_set) {
+        EDMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcb_block_kernel<C, L, SB, KC1, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        attr_set = true;
+    }
+    dim3 grid(1, (p.B + SB - 1) / SB);
+    hipLaunchKernelGGL((rcb_block_kernel<C, L, SB, KC1, RES>), grid, dim3(256), bytes, s, p);
+    return EDMP_OK;
+}
+// whole-residual-block kernel variants: (Cout, L, stored input channels) -> id (0 = none); odd ids carry the 1x1 residual conv
+static int blk_variant(int cout, int L, int c1, int c2, bool has_res) {
+    auto div = [&](int kc) { return c1 % kc == 0 && c2 % kc == 0 && c1 > 0; };
+    if (!has_res && (c2 != 0 || c1 != cout)) return 0;
+    int base = 0;
+    if (cout == 32 && L == 50) base = (c1 == 8 && c2 == 0) ? 1 : (div(32) ? 3 : 0);
+    else if (cout == 64 && L == 25 && div(16)) base = 5;
+    else if (cout == 64 && L == 13 && div(32)) base = 7;
+    else if (cout == 32 && L == 25 && div(32)) base = 9;
+    if (!base) return 0;
+    if (base == 1) return has_res ? 1 : 0;
+    return has_res ? base : base + 1;
+}
+static int launch_blk(const BlkP& p, int variant, hipStream_t s) {
+    switch (variant) {
+        case 1: return launch_blk_t<32, 50, 2, 8, true>(p, s);
+        case 3: return launch_blk_t<32, 50, 2, 32, true>(p, s);
+        case 4: return launch_blk_t<32, 50, 2, 32, false>(p, s);
+        case 5: return launch_blk_t<64, 25, 4, 16, true>(p, s);
+        case 6: return launch_blk_t<64, 25, 4, 16, false>(p, s);
+        case 7: return launch_blk_t<64, 13, 4, 32, true>(p, s);
+        case 8: return launch_blk_t<64, 13, 4, 32, false>(p, s);
+        case 9: return launch_blk_t<32, 25, 4, 32, true>(p, s);
+        case 10: return launch_blk_t<32, 25, 4, 32, false>(p, s);
+    }
+    set_error("no whole-block kernel variant %d", variant);
+    return EDMP_ERR_STATE;
+}
 static int launch_rcb(const RcbP& p, int L, hipStream_t s) {
     const int cg = p.Cout / 8;
     if (cg == 64 && L == 2) return launch_rcb_t<64, 2>(p, s);
@@ -1249,6 +1668,8 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
         int tb_off;
         double fn, fe;
         int branch;
+        size_t w2, b2, gamma2, beta2, wr, br;  // OP_BLK
+        int blk;
         // fused conv+gn (OP_RCB): uses src1/src2/C1/C2/Lin/Cout/w/b/dst + gamma/beta/res/tb_off
     };
     std::vector<POp> pops;
@@ -1345,6 +1766,39 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
         tb_cursor += r.cout;
         tw_all.insert(tw_all.end(), params + r.tw.off, params + r.tw.off + (size_t)r.cout * td);
         tb_all.insert(tb_all.end(), params + r.tb.off, params + r.tb.off + r.cout);
+        const int bv = (use_fused && getenv("EDMP_NO_BLOCK") == nullptr) ? blk_variant(r.cout, x.L, x.C, x2 ? x2->C : 0, r.has_res) : 0;
+        if (bv) {
+            POp o{};
+            o.kind = OP_BLK;
+            o.blk = bv;
+            o.src1 = x.buf;
+            o.C1 = x.C;
+            o.src2 = x2 ? x2->buf : -1;
+            o.C2 = x2 ? x2->C : 0;
+            o.Lin = x.L;
+            o.Lout = x.L;
+            o.Cout = r.cout;
+            o.w = w1;
+            o.b = b1;
+            o.gamma = g1;
+            o.beta = be1;
+            o.w2 = w2;
+            o.b2 = b2;
+            o.gamma2 = g2;
+            o.beta2 = be2;
+            o.tb_off = tb_off;
+            if (r.has_res) {
+                o.wr = pk.conv(params + r.rw.off, r.cout, r.cin, 1, cin_store);
+                o.br = pk.vec(params + r.rb.off, r.cout);
+            }
+            o.res = r.has_res ? 1 : 0;
+            o.dst = pool.get();
+            const double vp = (double)valid_pairs(x.L, x.L, 5, 1, 2, false);
+            o.fn = 2.0 * x.L * r.cout * 5.0 * ((double)r.cin + r.cout) + (r.has_res ? 2.0 * x.L * r.cout * (double)r.cin : 0.0);
+            o.fe = 2.0 * vp * r.cout * ((double)cin_store + r.cout) + (r.has_res ? 2.0 * x.L * r.cout * (double)cin_store : 0.0);
+            pops.push_back(o);
+            return TH{o.dst, r.cout, x.L};
+        }
         if (use_fused && (rcb_supported(r.cout, x.L, x.C, x2 ? x2->C : 0) || (rows_variant(r.cout, x.L, x.C, x2 ? x2->C : 0) && rows_variant(r.cout, x.L, r.cout, 0)))) {
             TH h = emit_fused(x, x2, r.cin, r.cout, w1, b1, g1, be1, -1, tb_off);
             int res_buf;
@@ -1463,7 +1917,7 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
     // allocate
     size_t max_lc = (size_t)N * CP0;
     for (auto& o : pops)
-        if (o.kind == OP_CONV || o.kind == OP_RCB) max_lc = std::max(max_lc, (size_t)o.Lout * o.Cout);
+        if (o.kind == OP_CONV || o.kind == OP_RCB || o.kind == OP_BLK) max_lc = std::max(max_lc, (size_t)o.Lout * o.Cout);
     u->buf_cap = max_lc * (size_t)max_batch;
     if (hipMalloc((void**)&u->wpack, pk.host.size() * sizeof(float)) != hipSuccess) {
         unet_destroy(u);
@@ -1510,6 +1964,30 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
             c.bias = u->wpack + o.b;
             c.dst = u->bufs[o.dst];
             c.Cout = o.Cout;
+            op.flops_nominal = o.fn;
+            op.flops_exec = o.fe;
+            u->flops_nominal += o.fn;
+            u->flops_exec += o.fe;
+        } else if (o.kind == OP_BLK) {
+            BlkP& c = op.bk;
+            c.src1 = u->bufs[o.src1];
+            c.src2 = o.src2 >= 0 ? u->bufs[o.src2] : nullptr;
+            c.C1 = o.C1;
+            c.C2 = o.C2;
+            c.W1 = u->wpack + o.w;
+            c.b1 = u->wpack + o.b;
+            c.g1 = u->wpack + o.gamma;
+            c.be1 = u->wpack + o.beta;
+            c.tb = nullptr;
+            c.W2 = u->wpack + o.w2;
+            c.b2 = u->wpack + o.b2;
+            c.g2 = u->wpack + o.gamma2;
+            c.be2 = u->wpack + o.beta2;
+            c.Wr = o.res ? u->wpack + o.wr : nullptr;
+            c.br = o.res ? u->wpack + o.br : nullptr;
+            c.dst = u->bufs[o.dst];
+            op.bk_variant = o.blk;
+            op.tb_off = o.tb_off;
             op.flops_nominal = o.fn;
             op.flops_exec = o.fe;
             u->flops_nominal += o.fn;
@@ -1581,7 +2059,28 @@ int unet_run_program(edmp_ctx* ctx, int B, int t) {
         } else if (op.branch == 3) {
             EDMP_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         }
-        if (op.kind == OP_RCB) {
+        if (op.kind == OP_BLK) {
+            BlkP p = op.bk;
+            p.B = B;
+            p.tb = trow + op.tb_off;
+            std::pair<hipEvent_t, hipEvent_t> ev{};
+            if (pf.on) {
+                if (!pf.pool.empty()) {
+                    ev = pf.pool.back();
+                    pf.pool.pop_back();
+                } else {
+                    EDMP_HIP_CHECK(hipEventCreate(&ev.first));
+                    EDMP_HIP_CHECK(hipEventCreate(&ev.second));
+                }
+                EDMP_HIP_CHECK(hipEventRecord(ev.first, s));
+            }
+            int rc = launch_blk(p, op.bk_variant, s);
+            if (rc) return rc;
+            if (pf.on) {
+                EDMP_HIP_CHECK(hipEventRecord(ev.second, s));
+                pf.pending.push_back(ev);
+            }
+        } else if (op.kind == OP_RCB) {
             RcbP p = op.rc;
             p.B = B;
             p.add_tb = op.tb_off >= 0 ? trow + op.tb_off : nullptr;
