@@ -68,16 +68,38 @@ class Diffusion:
             guide._set_rows(guidance_schedule if guidance_schedule is not None else guide._sched)
 
     def denoise_guided(self, model, guide, traj_len, num_channels, guidance_schedule, batch_size=1, start=None, goal=None,
-                       condition=True, benchmarking=False, *, noise=None, seed=0, t_stop=0, zero_row0=True, return_device=False, chunk_steps=16):
+                       condition=True, benchmarking=False, *, noise=None, seed=0, t_stop=0, zero_row0=True, return_device=False, chunk_steps=16, allreduce=None):
         """diffusion.py:300-356.  ``noise``: optional pre-drawn (T+1,B,C,N) f64 ndarray / device tensor (default:
         drawn from the global NumPy RNG in the reference's order); ``noise="device"`` draws z on the GPU (Philox,
-        ``seed``) — a non-parity mode without the host draw / upload.  Returns (B,C,N) f64 ndarray (a fresh copy)."""
+        ``seed``) — a non-parity mode without the host draw / upload.  ``allreduce(tensor)``: this call is one row shard
+        of a batch spread over several GPUs; the callable sums the f64 device scalar over ranks in place (see
+        edmp_amd.dist.allreduce_sum_).  Returns (B,C,N) f64 ndarray (a fresh copy)."""
         ctx = self.ctx
         self._prepare(model, guide, batch_size, guidance_schedule)
         _capi.check(ctx.lib.edmp_sampler_set_condition(ctx.h, 1 if condition else 0))
         s = np.ascontiguousarray(np.asarray(start, dtype=np.float64).reshape(-1))
         g = np.ascontiguousarray(np.asarray(goal, dtype=np.float64).reshape(-1))
         out = ctx.empty((batch_size, num_channels, traj_len), torch.float64)
+        if allreduce is not None:
+            # "one logical batch across GPUs": this rank holds a row shard of a larger reference batch; the only cross-row
+            # coupling, the whole-batch sum(g^2) (lib/guide.py:629), is summed over ranks between the two halves of every
+            # guided step.  Device-resident state, one pair of C calls per step.
+            if noise is None or isinstance(noise, str):
+                raise ValueError("sharded runs take an explicit noise array (this rank's rows of the global stream)")
+            nd = noise if (isinstance(noise, torch.Tensor) and noise.is_cuda) else ctx.to_dev(noise, torch.float64)
+            X = nd[0].clone()
+            if condition:
+                with torch.cuda.stream(ctx.stream):
+                    X[:, :, 0] = torch.as_tensor(s, device=ctx.device)
+                    X[:, :, -1] = torch.as_tensor(g, device=ctx.device)
+            for t in range(self.T, int(t_stop), -1):
+                _capi.check(ctx.lib.edmp_step_a_dev(ctx.h, ptr(X), ptr(nd[1 + (self.T - t)]), batch_size, t, _capi.as_pd(s), _capi.as_pd(g),
+                                                    1 if zero_row0 else 0, None, None), "edmp_step_a_dev")
+                if guide is not None and (t % 2) < 1 and t >= 5:
+                    ctx.sync()
+                    allreduce(self.sumsq_tensor())
+                _capi.check(ctx.lib.edmp_step_b_dev(ctx.h, ptr(X), batch_size, t, _capi.as_pd(s), _capi.as_pd(g), None), "edmp_step_b_dev")
+            return X if return_device else ctx.to_host(X)
         if isinstance(noise, str):
             if noise != "device":
                 raise ValueError("noise must be an array, a device tensor, None (NumPy stream) or 'device'")

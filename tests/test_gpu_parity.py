@@ -582,3 +582,83 @@ def test_error_behaviour_through_the_boundary():
     # the state is still usable after the failures
     X = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=4, start=scenes.DEFAULT_START, goal=scenes.DEFAULT_GOAL, noise="device", seed=2, t_stop=T - 2)
     assert np.isfinite(X).all()
+
+
+def _sharded_worker(rank, world, port, q):
+    import os
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from edmp_amd import dist as ED
+    from edmp_amd import scenes
+    from edmp_amd import weights as W
+    from edmp_amd.diffusion import Diffusion
+    from edmp_amd.guide import IntersectionVolumeGuide
+    from edmp_amd.temporalunet import TemporalUNet
+
+    guides, bpg = [1, 11, 18, 10], 3  # grad_norm rows (11, 18) make the cross-rank norm matter
+    cfgs = cfgs_for(guides, bpg)
+    Btot = cfgs["total_batch_size"]
+    lo, hi = ED.shard_rows(Btot, rank, world)
+    sh = ED.shard_guide_cfgs(cfgs, lo, hi)
+    net = TemporalUNet(None, 7, 32, DEV, dims=TINY_DIMS, state_dict=W.init_state_dict(5, 7, 32, TINY_DIMS), max_batch=Btot)
+    scene = scenes.random_scene(7, 8)
+    guide = IntersectionVolumeGuide(scene, DEV, sh, hi - lo)
+    dif = Diffusion(T, DEV)
+    noise = noise_for(41, Btot)
+    X = dif.denoise_guided(net, guide, 50, 7, sh["guidance_schedule"], batch_size=hi - lo, start=scenes.DEFAULT_START, goal=scenes.DEFAULT_GOAL,
+                           noise=np.ascontiguousarray(noise[:, lo:hi]), t_stop=T - 10, zero_row0=(rank == 0), allreduce=ED.allreduce_sum_)
+    vols, idx = guide.row_swept_volumes(scenes.DEFAULT_START, scenes.DEFAULT_GOAL, X)
+    best = ED.gather_best(float(vols[idx]), idx, X[idx], True)
+    q.put((rank, lo, hi, X, best["rank"], best["index"], best["volume"]))
+    dist.destroy_process_group()
+
+
+def test_one_logical_batch_sharded_over_two_ranks():
+    """BASELINE config 5 semantics: two processes each hold half the rows of ONE reference batch that has
+    grad_norm rows; with the per-guided-step all-reduce of sum(g^2) the shards reproduce the single-process run, and the
+    end-of-sampling gather picks the same row.  (gloo; both ranks share this box's GPU.)"""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from edmp_amd import scenes
+    from edmp_amd import weights as W
+    from edmp_amd.diffusion import Diffusion
+    from edmp_amd.guide import IntersectionVolumeGuide
+    from edmp_amd.temporalunet import TemporalUNet
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    out = sorted((q.get(timeout=300) for _ in range(2)), key=lambda o: o[0])
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfgs = cfgs_for([1, 11, 18, 10], 3)
+    B = cfgs["total_batch_size"]
+    net = TemporalUNet(None, 7, 32, DEV, dims=TINY_DIMS, state_dict=W.init_state_dict(5, 7, 32, TINY_DIMS), max_batch=B)
+    guide = IntersectionVolumeGuide(scenes.random_scene(7, 8), DEV, cfgs, B)
+    dif = Diffusion(T, DEV)
+    Xref = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=scenes.DEFAULT_START, goal=scenes.DEFAULT_GOAL,
+                              noise=noise_for(41, B), t_stop=T - 10)
+    Xsh = np.concatenate([out[0][3], out[1][3]], axis=0)
+    assert (out[0][1], out[0][2], out[1][1], out[1][2]) == (0, 6, 6, 12)
+    assert maxabs(Xsh, Xref) <= 1e-9, maxabs(Xsh, Xref)  # only the f64 summation order of sum(g^2) differs
+    vols, idx = guide.row_swept_volumes(scenes.DEFAULT_START, scenes.DEFAULT_GOAL, Xref)
+    owner, local = (0, idx) if idx < 6 else (1, idx - 6)
+    assert out[0][4] == out[1][4] == owner and out[0][5] == out[1][5] == local
+    # without the all-reduce the grad_norm rows would differ: the coupling is real
+    g2 = IntersectionVolumeGuide(scenes.random_scene(7, 8), DEV, {k: (v[:6] if hasattr(v, "shape") and v.shape[:1] == (12,) else v) for k, v in cfgs.items()}, 6)
+    Xno = dif.denoise_guided(net, g2, 50, 7, cfgs["guidance_schedule"][:6], batch_size=6, start=scenes.DEFAULT_START, goal=scenes.DEFAULT_GOAL,
+                             noise=np.ascontiguousarray(noise_for(41, B)[:, :6]), t_stop=T - 10)
+    assert maxabs(Xno, Xref[:6]) > 1e-6
