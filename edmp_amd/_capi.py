@@ -60,6 +60,8 @@ SIGNATURES = {
     "edmp_denoise_guided_segment_dev": (_i, [_vp, _vp, _i, _pd, _pd, _i, _i, _i, _i, _i, _vp]),
     "edmp_denoise_guided_rng_dev": (_i, [_vp, C.c_uint64, _i, _pd, _pd, _i, _i, _i, _vp]),
     "edmp_rng_normal_dev": (_i, [_vp, C.c_uint64, _i, _i, _i, _i, _vp]),
+    "edmp_sampler_set_graph": (_i, [_vp, _i]),
+    "edmp_q_sample_dev": (_i, [_vp, _vp, _vp, _pi32, _i, _i, _i, _i, _i, _vp, _vp]),
     "edmp_prof_enable": (_i, [_vp, _i]),
     "edmp_prof_read": (_i, [_vp, _pd, C.POINTER(C.c_int64), _i]),
 }

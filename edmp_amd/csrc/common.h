@@ -66,6 +66,7 @@ struct edmp_ctx {
     edmp::Guide* guide = nullptr;
     edmp::Sampler* sampler = nullptr;
     edmp::Prof prof;
+    uint64_t epoch = 0;  // bumped whenever device pointers / tables a captured hipGraph baked in may have changed
 };
 
 namespace edmp {

@@ -486,6 +486,14 @@ static int launch_guide(edmp_ctx* ctx, const TIn* joints, int ldw, int off, int 
 }
 
 // entry points used by sampler.hip
+int guide_prepare(edmp_ctx* ctx, int B, int L) {  // allocate the step scratch up front (nothing may allocate inside a graph capture)
+    Guide* g = ctx->guide;
+    EDMP_REQUIRE(g, "scene/rows not set");
+    const float* before = g->graw;
+    int rc = ensure_scratch(g, B, L);
+    if (g->graw != before) ctx->epoch++;
+    return rc;
+}
 int guide_raw_gradient_from_X(edmp_ctx* ctx, const double* X_dev, int B, int N, int t) {
     Guide* g = ctx->guide;
     EDMP_REQUIRE(g && g->aabb && g->row_class, "scene/rows not set");
@@ -538,6 +546,7 @@ extern "C" int edmp_scene_set(edmp_ctx* ctx, const double* obstacle_config, int 
                               int T, const float* link_half_extents, const float* dh, const float* static_frames) {
     EDMP_REQUIRE(ctx && obstacle_config && clearance && expansion && link_half_extents && dh && static_frames, "edmp_scene_set: null argument");
     EDMP_REQUIRE(no >= 1 && no <= EDMP_MAX_OBSTACLES, "n_obstacles %d outside 1..%d", no, EDMP_MAX_OBSTACLES);
+    ctx->epoch++;
     EDMP_REQUIRE(G >= 1 && T >= 1, "need at least one guide class and one step");
     EDMP_HIP_CHECK(hipSetDevice(ctx->device));
     if (!ctx->guide) {
@@ -602,6 +611,7 @@ extern "C" int edmp_rows_set(edmp_ctx* ctx, const int32_t* row_class, const floa
                              int T) {
     EDMP_REQUIRE(ctx && ctx->guide && ctx->guide->aabb, "edmp_rows_set: call edmp_scene_set first");
     EDMP_REQUIRE(row_class && method && grad_norm && sched && B >= 1, "edmp_rows_set: null argument");
+    ctx->epoch++;
     Guide* g = ctx->guide;
     for (int i = 0; i < B; ++i) {
         EDMP_REQUIRE(row_class[i] >= 0 && row_class[i] < g->G, "row %d: class %d outside 0..%d", i, row_class[i], g->G - 1);

@@ -23,6 +23,7 @@ int unet_forward_impl(edmp_ctx* ctx, const float* x_dev, int B, int t, float* ep
 int unet_run_program(edmp_ctx* ctx, int B, int t);
 int guide_raw_gradient_from_X(edmp_ctx* ctx, const double* X_dev, int B, int N, int t);
 int guide_set_startgoal(edmp_ctx* ctx, const double* start, const double* goal);
+int guide_prepare(edmp_ctx* ctx, int B, int L);
 const float* guide_graw(edmp_ctx* ctx);
 const double* guide_grad_norm(edmp_ctx* ctx);
 const double* guide_sched(edmp_ctx* ctx);
@@ -38,12 +39,30 @@ struct Sampler {
     int run_B = 0;          // batch of the run whose state sits in X (segmented runs)
     int condition = 1;      // pin X[:, :, 0] / X[:, :, -1] to start / goal (diffusion.py:305-307, 347-349)
     int cap = 0;            // elements
+    // whole-run hipGraph (EDMP_GRAPH=1): the enqueue of one denoise_loop call captured once and replayed while the
+    // call's arguments stay the same (start/goal travel through `sg`, so they are not part of the key)
+    struct GraphKey {
+        const void* noise = nullptr;
+        uint64_t seed = 0;
+        int use_rng = 0, B = 0, guided = 0, t_hi = 0, t_lo = 0, init = 0, zero_row0 = 0, condition = 0;
+        uint64_t epoch = 0;  // bumped by anything that invalidates captured pointers/arguments (scene, rows, weights)
+        bool operator==(const GraphKey& o) const {
+            return noise == o.noise && seed == o.seed && use_rng == o.use_rng && B == o.B && guided == o.guided && t_hi == o.t_hi &&
+                   t_lo == o.t_lo && init == o.init && zero_row0 == o.zero_row0 && condition == o.condition && epoch == o.epoch;
+        }
+    } gkey;
+    hipGraphExec_t gexec = nullptr;
+    int graph_on = -1;  // -1 = read EDMP_GRAPH on first use
+    int graph_captures = 0, graph_replays = 0;
+    double* qcoef = nullptr;  // [B][2] sqrt(a), sqrt(1 - a) of edmp_q_sample_dev
+    int qcoef_cap = 0;
 };
 
 void sampler_destroy(Sampler* s) {
     if (!s) return;
-    for (void* p : {(void*)s->X, (void*)s->sg})
+    for (void* p : {(void*)s->X, (void*)s->sg, (void*)s->qcoef})
         if (p) (void)hipFree(p);
+    if (s->gexec) (void)hipGraphExecDestroy(s->gexec);
     delete s;
 }
 
@@ -268,9 +287,26 @@ __global__ __launch_bounds__(256) void head_psample_kernel(const float* __restri
     }
 }
 
+// forward process: xt = sa*x + sb*eps per row (coef = [B][2]); products and sum rounded separately (NumPy's evaluation)
+__global__ void q_sample_kernel(const double* __restrict__ x, const double* __restrict__ eps, const double* __restrict__ coef,
+                                double* __restrict__ xt, double* __restrict__ mean, int n, int per_row, int N, int condition) {
+#pragma clang fp contract(off)  // hipcc fuses a*b + c into an FMA by default (and __dmul_rn / __dadd_rn are plain * and +)
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = i / per_row, w = i % N;
+    const double xv = x[i];
+    const double m = coef[2 * b] * xv;
+    const double e = coef[2 * b + 1] * eps[i];
+    double v = m + e;
+    if (condition && (w == 0 || w == N - 1)) v = xv;
+    xt[i] = v;
+    if (mean) mean[i] = m;
+}
+
 static int ensure_sampler_scratch(edmp_ctx* ctx, int n) {
     Sampler* s = ctx->sampler;
     if (s->cap >= n) return EDMP_OK;
+    ctx->epoch++;
     if (s->X) (void)hipFree(s->X);
     s->X = nullptr;
     EDMP_HIP_CHECK(hipMalloc((void**)&s->X, (size_t)n * sizeof(double)));
@@ -411,6 +447,7 @@ extern "C" int edmp_ctx_set_stream(edmp_ctx* ctx, void* hip_stream) {
     EDMP_REQUIRE(ctx, "null ctx");
     EDMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    ctx->epoch++;
     return EDMP_OK;
 }
 
@@ -423,6 +460,7 @@ extern "C" int edmp_ctx_synchronize(edmp_ctx* ctx) {
 
 extern "C" int edmp_sampler_init(edmp_ctx* ctx, int T, double variance_thresh) {
     EDMP_REQUIRE(ctx && T >= 1, "edmp_sampler_init: bad arguments");
+    ctx->epoch++;
     EDMP_HIP_CHECK(hipSetDevice(ctx->device));
     if (!ctx->sampler) {
         ctx->sampler = new Sampler();
@@ -519,6 +557,37 @@ extern "C" double* edmp_sumsq_ptr_dev(edmp_ctx* ctx) { return ctx ? guide_sumsq(
 // this segment consumes: [X_T draw if init][z of step t_hi][z of step t_hi-1]...  X_out_dev may be NULL (segment in the
 // middle of a chunked run).  A continuation segment performs no host<->device synchronisation, so a caller can draw and
 // upload the next chunk of the NumPy noise stream while this one computes.
+// the stream work of one denoise_loop call: no host synchronisation, no allocation (capturable into a hipGraph)
+static int enqueue_loop(edmp_ctx* ctx, const double* noise_dev, bool use_rng, uint64_t seed, int B, int guided, int t_hi, int t_lo, bool init,
+                        int zero_row0, double* X_out_dev) {
+    Sampler* s = ctx->sampler;
+    const int C = ctx->unet->desc.input_dim, N = ctx->unet->desc.horizon;
+    const size_t n = (size_t)B * C * N;
+    hipStream_t st = ctx->stream;
+    int rc;
+    if (init) {
+        // X_T with start/goal conditioning                                              diffusion.py:303-307
+        if (use_rng) {
+            hipLaunchKernelGGL(init_state_rng_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, seed, s->X, ctx->unet->x_in, s->sg, B, C, N,
+                               s->condition);
+        } else {
+            EDMP_HIP_CHECK(hipMemcpyAsync(s->X, noise_dev, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+            if (s->condition) hipLaunchKernelGGL(condition_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, s->X, B, C, N, s->sg);
+            hipLaunchKernelGGL(pack_state_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, s->X, ctx->unet->x_in, B, C, N);
+            noise_dev += n;
+        }
+    }
+    for (int t = t_hi; t > t_lo; --t) {
+        const double* z = use_rng ? nullptr : noise_dev + (size_t)(t_hi - t) * n;
+        rc = step_a(ctx, s->X, z, B, t, zero_row0, guided, nullptr, nullptr, true, use_rng, seed);
+        if (rc) return rc;
+        rc = step_b(ctx, s->X, B, t, guided, nullptr, true);
+        if (rc) return rc;
+    }
+    if (X_out_dev) EDMP_HIP_CHECK(hipMemcpyAsync(X_out_dev, s->X, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return EDMP_OK;
+}
+
 static int denoise_loop(edmp_ctx* ctx, const double* noise_dev, bool use_rng, uint64_t seed, int B, const double* start, const double* goal,
                         int guided, int t_hi, int t_lo, bool init, int zero_row0, double* X_out_dev) {
     int rc = check_loop_state(ctx, B, guided != 0);
@@ -539,28 +608,54 @@ static int denoise_loop(edmp_ctx* ctx, const double* noise_dev, bool use_rng, ui
         rc = set_startgoal(ctx, start, goal, guided != 0);
         if (rc) return rc;
         s->run_B = B;
-        // X_T with start/goal conditioning                                              diffusion.py:303-307
-        if (use_rng) {
-            hipLaunchKernelGGL(init_state_rng_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, seed, s->X, ctx->unet->x_in, s->sg, B, C, N,
-                               s->condition);
-        } else {
-            EDMP_HIP_CHECK(hipMemcpyAsync(s->X, noise_dev, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-            if (s->condition) hipLaunchKernelGGL(condition_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, s->X, B, C, N, s->sg);
-            hipLaunchKernelGGL(pack_state_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, s->X, ctx->unet->x_in, B, C, N);
-            noise_dev += n;
-        }
     } else {
         EDMP_REQUIRE(s->X && s->run_B == B, "no run in progress for batch %d (call with init first)", B);
     }
-    for (int t = t_hi; t > t_lo; --t) {
-        const double* z = use_rng ? nullptr : noise_dev + (size_t)(t_hi - t) * n;
-        rc = step_a(ctx, s->X, z, B, t, zero_row0, guided, nullptr, nullptr, true, use_rng, seed);
-        if (rc) return rc;
-        rc = step_b(ctx, s->X, B, t, guided, nullptr, true);
-        if (rc) return rc;
+    if (s->graph_on < 0) {
+        const char* e = getenv("EDMP_GRAPH");
+        s->graph_on = (e && e[0] && e[0] != '0') ? 1 : 0;
     }
-    if (X_out_dev) EDMP_HIP_CHECK(hipMemcpyAsync(X_out_dev, s->X, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-    return EDMP_OK;
+    const bool graph = s->graph_on == 1 && !ctx->prof.on;
+    Sampler::GraphKey key;
+    if (graph) {
+        if (guided) {
+            rc = guide_prepare(ctx, B, N - 2);
+            if (rc) return rc;
+        }
+        key.noise = noise_dev, key.seed = seed, key.use_rng = use_rng, key.B = B, key.guided = guided, key.t_hi = t_hi, key.t_lo = t_lo;
+        key.init = init, key.zero_row0 = zero_row0, key.condition = s->condition, key.epoch = ctx->epoch;
+        if (s->gexec && key == s->gkey) {
+            s->graph_replays++;
+            EDMP_HIP_CHECK(hipGraphLaunch(s->gexec, st));
+            if (X_out_dev) EDMP_HIP_CHECK(hipMemcpyAsync(X_out_dev, s->X, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+            return EDMP_OK;
+        }
+        if (s->gexec) {
+            (void)hipGraphExecDestroy(s->gexec);
+            s->gexec = nullptr;
+        }
+        EDMP_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    }
+    // the copy-out stays outside the graph: callers hand a fresh output buffer to every call
+    rc = enqueue_loop(ctx, noise_dev, use_rng, seed, B, guided, t_hi, t_lo, init, zero_row0, graph ? nullptr : X_out_dev);
+    if (graph) {
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(st, &g);
+        if (rc) {
+            if (g) (void)hipGraphDestroy(g);
+            return rc;
+        }
+        EDMP_HIP_CHECK(e);
+        e = hipGraphInstantiate(&s->gexec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        EDMP_HIP_CHECK(e);
+        s->gkey = key;
+        s->graph_captures++;
+        if (getenv("EDMP_GRAPH_DEBUG")) fprintf(stderr, "[edmp] captured run graph #%d (replays so far %d)\n", s->graph_captures, s->graph_replays);
+        EDMP_HIP_CHECK(hipGraphLaunch(s->gexec, st));
+        if (X_out_dev) EDMP_HIP_CHECK(hipMemcpyAsync(X_out_dev, s->X, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    return rc;
 }
 
 extern "C" int edmp_denoise_guided_dev(edmp_ctx* ctx, const double* noise_dev, int B, const double* start, const double* goal, int guided,
@@ -580,6 +675,43 @@ extern "C" int edmp_denoise_guided_segment_dev(edmp_ctx* ctx, const double* nois
                                                int t_hi, int t_lo, int init, int zero_row0, double* X_out_dev) {
     EDMP_REQUIRE(ctx && ctx->sampler && noise_dev, "edmp_denoise_guided_segment_dev: bad arguments");
     return denoise_loop(ctx, noise_dev, false, 0, B, start, goal, guided, t_hi, t_lo, init != 0, zero_row0, X_out_dev);
+}
+
+extern "C" int edmp_sampler_set_graph(edmp_ctx* ctx, int on) {
+    EDMP_REQUIRE(ctx && ctx->sampler, "sampler not initialised");
+    ctx->sampler->graph_on = on ? 1 : 0;
+    return EDMP_OK;
+}
+
+extern "C" int edmp_q_sample_dev(edmp_ctx* ctx, const double* x_dev, const double* eps_dev, const int32_t* t_host, int B, int C, int N,
+                                 int cumulative, int condition, double* xt_dev, double* mean_dev) {
+    EDMP_REQUIRE(ctx && ctx->sampler, "sampler not initialised");
+    EDMP_REQUIRE(x_dev && eps_dev && t_host && xt_dev, "edmp_q_sample_dev: null pointer");
+    EDMP_REQUIRE(B >= 1 && C >= 1 && N >= 1, "edmp_q_sample_dev: bad shape (%d,%d,%d)", B, C, N);
+    Sampler* s = ctx->sampler;
+    EDMP_HIP_CHECK(hipSetDevice(ctx->device));
+    std::vector<double> coef((size_t)B * 2);
+    const std::vector<double>& a = cumulative ? s->alpha_bar : s->alpha;
+    for (int b = 0; b < B; ++b) {
+        EDMP_REQUIRE(t_host[b] >= 1 && t_host[b] <= s->T, "row %d: timestep %d outside 1..%d", b, t_host[b], s->T);
+        coef[2 * b] = sqrt(a[t_host[b] - 1]);
+        coef[2 * b + 1] = sqrt(1.0 - a[t_host[b] - 1]);
+    }
+    if (s->qcoef_cap < B) {
+        if (s->qcoef) (void)hipFree(s->qcoef);
+        s->qcoef = nullptr;
+        s->qcoef_cap = 0;
+        EDMP_HIP_CHECK(hipMalloc((void**)&s->qcoef, (size_t)B * 2 * sizeof(double)));
+        s->qcoef_cap = B;
+    }
+    // the previous call's kernel may still be reading qcoef, and `coef` dies with this frame: order both on the stream
+    EDMP_HIP_CHECK(hipMemcpyAsync(s->qcoef, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    EDMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const int n = B * C * N;
+    hipLaunchKernelGGL(q_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, x_dev, eps_dev, s->qcoef, xt_dev, mean_dev, n, C * N, N,
+                       condition);
+    EDMP_HIP_CHECK(hipGetLastError());
+    return EDMP_OK;
 }
 
 extern "C" int edmp_rng_normal_dev(edmp_ctx* ctx, uint64_t seed, int step_index, int B, int C, int N, double* out_dev) {

@@ -1632,6 +1632,7 @@ extern "C" int64_t edmp_unet_param_count(const edmp_unet_desc* desc) {
 
 extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* params, int64_t n_params, int max_batch) {
     EDMP_REQUIRE(ctx && desc && params, "edmp_unet_load: null argument");
+    ctx->epoch++;
     EDMP_REQUIRE(desc->n_levels >= 2 && desc->n_levels <= EDMP_MAX_LEVELS, "n_levels out of range");
     EDMP_REQUIRE(desc->input_dim >= 1 && desc->input_dim <= 8, "input_dim must be in 1..8");
     EDMP_REQUIRE(desc->time_dim >= 4 && desc->time_dim % 2 == 0, "time_dim must be even");

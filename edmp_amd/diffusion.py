@@ -50,6 +50,53 @@ class Diffusion:
         _capi.check(ctx.lib.edmp_psample_dev(ctx.h, ptr(X), ptr(e), ptr(zd), b, c, n, int(t), 1), "edmp_psample_dev")
         return ctx.to_host(X)
 
+    # ---- forward process (training-side data generation) -------------------------------------------------------
+    def _q(self, x, t, eps, cumulative, condition=False):
+        ctx = self.ctx
+        ctx.ensure_sampler(self.T, self.variance_thresh)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        b, c, n = x.shape
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(t), (b,)), dtype=np.int32)
+        if eps is None:  # diffusion.py:68-71 / 95-98: an identity-covariance multivariate normal == standard normal draws
+            eps = np.random.standard_normal((b, c * n)).reshape(b, c, n)
+        xd = ctx.to_dev(x, torch.float64)
+        ed = ctx.to_dev(np.ascontiguousarray(eps, dtype=np.float64), torch.float64)
+        xt = ctx.empty((b, c, n), torch.float64)
+        mean = ctx.empty((b, c, n), torch.float64)
+        _capi.check(ctx.lib.edmp_q_sample_dev(ctx.h, ptr(xd), ptr(ed), _capi.as_pi32(t), b, c, n, int(cumulative), int(bool(condition)), ptr(xt),
+                                              ptr(mean)), "edmp_q_sample_dev")
+        return ctx.to_host(xt), ctx.to_host(mean), t
+
+    def q_sample(self, x, t, eps=None):
+        """q(x_t | x_{t-1}) (diffusion.py:52-77): (xt, mean, var)."""
+        xt, mean, t = self._q(x, t, eps, cumulative=0)
+        return xt, mean, np.sqrt(1 - self.alpha[t - 1])
+
+    def q_sample_from_x0(self, x0, t, eps=None):
+        """q(x_t | x_0) (diffusion.py:79-105): (xt, mean, var), var of shape (b,1,1) like the reference."""
+        xt, mean, t = self._q(x0, t, eps, cumulative=1)
+        return xt, mean, np.sqrt(1 - self.alpha_bar[t - 1, np.newaxis, np.newaxis])
+
+    def generate_q_sample(self, x0, time_steps=None, condition=True, return_type="tensor"):
+        """Training pairs (diffusion.py:201-251): random timesteps + noise from the global NumPy RNG in the reference's
+        order, diffusion and conditioning on the GPU.  Returns (X, Y, time_steps, means, vars)."""
+        b, c, n = x0.shape
+        if time_steps is None:
+            time_steps = np.random.randint(1, self.T + 1, size=(b,))
+        eps = np.random.standard_normal((b, c, n))  # == multivariate_normal(0, I_n, size=(b, c))   (diffusion.py:231)
+        xt, means, t = self._q(x0, time_steps, eps, cumulative=1, condition=condition)
+        vars_ = np.sqrt(1 - self.alpha_bar[t - 1, np.newaxis, np.newaxis])
+        if return_type == "tensor":
+            return torch.tensor(xt, dtype=torch.float32), torch.tensor(eps, dtype=torch.float32), torch.tensor(time_steps, dtype=torch.float32), means, vars_
+        if return_type == "numpy":
+            return xt, eps.copy(), time_steps, means, vars_
+        raise ValueError('return_type must be "tensor" or "numpy"')  # the reference falls through to a NameError here
+
+    def set_graph_replay(self, on: bool):
+        """Capture the device-resident loop of denoise_guided into a hipGraph and replay it (see edmp_sampler_set_graph)."""
+        self.ctx.ensure_sampler(self.T, self.variance_thresh)
+        _capi.check(self.ctx.lib.edmp_sampler_set_graph(self.ctx.h, 1 if on else 0))
+
     def clip_joints(self, joints):
         lo, hi = franka.joint_limits()
         return np.clip(joints, lo[np.newaxis, :, np.newaxis], hi[np.newaxis, :, np.newaxis])

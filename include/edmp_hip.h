@@ -148,6 +148,23 @@ int edmp_denoise_guided_rng_dev(edmp_ctx* ctx, uint64_t seed, int B, const doubl
                                 int t_stop, int zero_row0, double* X_out_dev);
 int edmp_rng_normal_dev(edmp_ctx* ctx, uint64_t seed, int step_index, int B, int C, int N, double* out_dev);
 
+/* Replay mode of the device-resident loop: on = 1 captures the stream work of one edmp_denoise_guided*_dev call
+ * (255 reverse steps, ~16k kernel nodes) into a hipGraph the first time and replays it while the call's arguments,
+ * scene, rows and weights stay the same (start/goal are read from a device buffer and may change freely).  Results are
+ * bit-identical to the eager enqueue.  Off by default (also switched on by the environment variable EDMP_GRAPH=1):
+ * measured neutral on MI355X at B = 4..1024 - the loop is bound by kernel execution, not by launch. */
+int edmp_sampler_set_graph(edmp_ctx* ctx, int on);
+
+/* ---- training-side forward process --------------------------------------------------------- */
+/* replaces the arithmetic of Diffusion.q_sample (diffusion/diffusion.py:52-77, cumulative = 0: a = alpha),
+ * Diffusion.q_sample_from_x0 (:79-105, cumulative = 1: a = alpha_bar) and the conditioning of generate_q_sample
+ * (:239-242):   xt = sqrt(a[t_b - 1]) * x + sqrt(1 - a[t_b - 1]) * eps,   mean = sqrt(a[t_b - 1]) * x
+ * with one timestep per row (t_host: B int32 on the HOST, each in 1..T); condition != 0 then pins xt[:, :, 0] and
+ * xt[:, :, -1] to x.  x, eps, xt, mean: (B,C,N) f64 on the device; mean_dev may be NULL.  Rounded like NumPy's f64
+ * expression (two products, one sum, no FMA contraction), so results are bit-identical to the reference's. */
+int edmp_q_sample_dev(edmp_ctx* ctx, const double* x_dev, const double* eps_dev, const int32_t* t_host, int B, int C, int N,
+                      int cumulative, int condition, double* xt_dev, double* mean_dev);
+
 /* ---- instrumentation ----------------------------------------------------------------------------------- */
 /* accumulate HIP-event time of the dominant kernel family (the MFMA conv kernels) while enabled */
 int edmp_prof_enable(edmp_ctx* ctx, int on);

@@ -53,6 +53,43 @@ def p_sample_using_posterior(xt, t, eps, z, beta, alpha, alpha_bar):
 
 
 # --------------------------------------------------------------------------------------------------------------
+# f4  forward process (training-side data generation)        diffusion/diffusion.py:52-105, 201-251
+# --------------------------------------------------------------------------------------------------------------
+
+
+def q_sample(x, t, eps, alpha):
+    """one forward step q(x_t | x_{t-1}): (xt, mean, var) of diffusion.py:72-76; ``t`` an int array (b,)."""
+    t = np.asarray(t)
+    a = alpha[t - 1, np.newaxis, np.newaxis]
+    xt = np.sqrt(a) * x + np.sqrt(1 - a) * eps
+    return xt, np.sqrt(a) * x, np.sqrt(1 - alpha[t - 1])
+
+
+def q_sample_from_x0(x0, t, eps, alpha_bar):
+    """q(x_t | x_0): (xt, mean, var) of diffusion.py:100-104 (var keeps the (b,1,1) shape the reference returns)."""
+    t = np.asarray(t)
+    ab = alpha_bar[t - 1, np.newaxis, np.newaxis]
+    xt = np.sqrt(ab) * x0 + np.sqrt(1 - ab) * eps
+    return xt, np.sqrt(ab) * x0, np.sqrt(1 - ab)
+
+
+def generate_q_sample(x0, T, alpha_bar, time_steps=None, condition=True):
+    """diffusion.py:201-251 with return_type="numpy": draws (global NumPy RNG, reference order) the timesteps
+    ``randint(1, T+1, (b,))`` unless given, then eps = multivariate_normal(0, I_n, (b, c)) (== standard_normal((b,c,n))
+    for an identity covariance), diffuses, and pins the first / last waypoint to x0 when ``condition``.
+    Returns (X, Y, time_steps, means, vars)."""
+    b, c, n = x0.shape
+    if time_steps is None:
+        time_steps = np.random.randint(1, T + 1, size=(b,))
+    eps = np.random.standard_normal((b, c, n))
+    xt, means, vars_ = q_sample_from_x0(x0, time_steps, eps, alpha_bar)
+    if condition:
+        xt[:, :, 0] = x0[:, :, 0].copy()
+        xt[:, :, -1] = x0[:, :, -1].copy()
+    return xt.copy(), eps.copy(), time_steps, means, vars_
+
+
+# --------------------------------------------------------------------------------------------------------------
 # a3  joint clip                                                                      diffusion/diffusion.py:280-298
 # --------------------------------------------------------------------------------------------------------------
 

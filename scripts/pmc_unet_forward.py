@@ -11,7 +11,7 @@ from edmp_amd import _capi
 from edmp_amd.runtime import ptr
 from edmp_amd.temporalunet import TemporalUNet
 
-B = 1024
+B = int(os.environ.get("EDMP_PMC_BATCH", "1024"))
 net = TemporalUNet(None, 7, 32, "cuda:0", dims=(32, 64, 128, 256, 512, 512), seed=1, max_batch=B)
 ctx = net.ctx
 x = ctx.to_dev(torch.randn(B, 7, 50), torch.float32)

@@ -254,6 +254,73 @@ def test_teacher_forced_steps(golden, tiny_net, tag):
     assert worst <= 2e-5, worst  # what we actually achieve
 
 
+def test_forward_process_golden(golden):
+    """q_sample / q_sample_from_x0 / generate_q_sample on the GPU == the reference's f64 outputs, bit for bit, with the
+    global NumPy RNG consumed in the reference's order."""
+    from edmp_amd.diffusion import Diffusion
+
+    d = Diffusion(T, DEV)
+    g = golden("g12_qsample")
+    np.random.seed(int(g["gq_seed"]))
+    X, Y, ts, means, vars_ = d.generate_q_sample(g["x0"].copy(), return_type="numpy")
+    for a, k in ((X, "gq_X"), (Y, "gq_Y"), (ts, "gq_t"), (means, "gq_means"), (vars_, "gq_vars")):
+        assert np.array_equal(a, g[k]), k
+    np.random.seed(int(g["gq2_seed"]))
+    X2, Y2, _, means2, vars2 = d.generate_q_sample(g["x0"].copy(), time_steps=g["gq2_t"], condition=False, return_type="numpy")
+    for a, k in ((X2, "gq2_X"), (Y2, "gq2_Y"), (means2, "gq2_means"), (vars2, "gq2_vars")):
+        assert np.array_equal(a, g[k]), k
+    np.random.seed(int(g["gq3_seed"]))
+    Xt, Yt, tt, _, _ = d.generate_q_sample(g["x0"].copy())
+    assert Xt.dtype == torch.float32 and np.array_equal(Xt.numpy(), g["gq3_X32"]) and np.array_equal(Yt.numpy(), g["gq3_Y32"])
+    assert np.array_equal(tt.numpy(), g["gq3_t32"])
+    xs, ms, vs = d.q_sample(g["x0"], g["qs_t"], g["qs_eps"])
+    assert np.array_equal(xs, g["qs_xt"]) and np.array_equal(ms, g["qs_mean"]) and np.array_equal(vs, g["qs_var"])
+    np.random.seed(int(g["q0_seed"]))
+    assert np.array_equal(d.q_sample_from_x0(g["x0"], g["qs_t"])[0], g["q0_xt"])
+    # scalar timestep broadcast + error behaviour at the boundary
+    x1, _, v1 = d.q_sample_from_x0(g["x0"], 255, g["qs_eps"])
+    assert np.array_equal(x1, np.sqrt(d.alpha_bar[254]) * g["x0"] + np.sqrt(1 - d.alpha_bar[254]) * g["qs_eps"]) and v1.shape == (6, 1, 1)
+    from edmp_amd._capi import EdmpError
+
+    with pytest.raises(EdmpError, match="outside 1"):
+        d.q_sample(g["x0"], 0, g["qs_eps"])
+    with pytest.raises(EdmpError, match="outside 1"):
+        d.q_sample(g["x0"], 256, g["qs_eps"])
+
+
+def test_graph_replay_is_bit_identical(golden, tiny_net):
+    """edmp_sampler_set_graph: the captured + replayed loop gives exactly the eager loop's trajectories, keeps doing so
+    when start / goal change between replays, and re-captures when the scene or the rows change."""
+    from edmp_amd.diffusion import Diffusion
+    from edmp_amd.guide import IntersectionVolumeGuide
+
+    net, _ = tiny_net
+    g = golden("g9_trace_mixed_b12")
+    cfgs = cfgs_for(g["guides"], g["bpg"])
+    B = cfgs["total_batch_size"]
+    guide = IntersectionVolumeGuide(g["scene"], DEV, cfgs, B)
+    dif = Diffusion(T, DEV)
+    noise = dif.ctx.to_dev(noise_for(5, B), torch.float64)
+    run = lambda s, e: dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=s, goal=e, noise=noise)  # noqa: E731
+    goal2 = g["goal"] * 0.5
+    eager = [run(g["start"], g["goal"]), run(g["start"], goal2)]
+    dif.set_graph_replay(True)
+    try:
+        assert np.array_equal(run(g["start"], g["goal"]), eager[0])  # capture + first launch
+        assert np.array_equal(run(g["start"], g["goal"]), eager[0])  # replay
+        assert np.array_equal(run(g["start"], goal2), eager[1])      # replay with another goal (device-side start/goal)
+        from edmp_amd import scenes
+
+        scene2 = scenes.random_scene(3, 8)
+        guide2 = IntersectionVolumeGuide(scene2, DEV, cfgs, B)        # new obstacle table: the graph must be re-captured
+        got = dif.denoise_guided(net, guide2, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=g["start"], goal=g["goal"], noise=noise)
+    finally:
+        dif.set_graph_replay(False)
+    want = dif.denoise_guided(net, guide2, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=g["start"], goal=g["goal"], noise=noise)
+    assert np.array_equal(got, want)
+    assert not np.array_equal(got, eager[0])
+
+
 def test_free_running_unguided(oracle, tiny_net):
     """guide off: the loop is contractive, so 255 free-running steps must track the oracle."""
     from edmp_amd.diffusion import Diffusion

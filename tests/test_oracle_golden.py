@@ -140,3 +140,20 @@ def test_g11_ik(golden):
     og = O.GuideOracle(g["scene"], cfgs, 12)
     v = og.cost(g["ik"].reshape((-1, 7, 1)), 0, batch_size=g["ik"].shape[0]).sum(axis=(1, 2)).numpy()
     assert maxabs(v, g["volumes"]) <= 1e-7
+
+
+def test_g12_forward_process(golden):
+    """training-side forward process: oracle == reference outputs, bit for bit."""
+    g = golden("g12_qsample")
+    _, alpha, alpha_bar = O.schedule(T)
+    np.random.seed(int(g["gq_seed"]))
+    X, Y, ts, means, vars_ = O.generate_q_sample(g["x0"].copy(), T, alpha_bar)
+    for a, k in ((X, "gq_X"), (Y, "gq_Y"), (ts, "gq_t"), (means, "gq_means"), (vars_, "gq_vars")):
+        assert np.array_equal(a, g[k]), k
+    assert np.array_equal(X[:, :, 0], g["x0"][:, :, 0]) and np.array_equal(X[:, :, -1], g["x0"][:, :, -1])  # conditioning
+    np.random.seed(int(g["gq2_seed"]))
+    X2, Y2, _, means2, vars2 = O.generate_q_sample(g["x0"].copy(), T, alpha_bar, time_steps=g["gq2_t"], condition=False)
+    for a, k in ((X2, "gq2_X"), (Y2, "gq2_Y"), (means2, "gq2_means"), (vars2, "gq2_vars")):
+        assert np.array_equal(a, g[k]), k
+    xs, ms, vs = O.q_sample(g["x0"], g["qs_t"], g["qs_eps"], alpha)
+    assert np.array_equal(xs, g["qs_xt"]) and np.array_equal(ms, g["qs_mean"]) and np.array_equal(vs, g["qs_var"])
