@@ -44,7 +44,7 @@ class Diffusion:
         b, c, n = xt.shape
         if z is None:
             z = np.random.standard_normal((b, c, n))
-        X = ctx.to_dev(np.asarray(xt, dtype=np.float64), torch.float64).clone()
+        X = ctx.to_dev(np.array(xt, dtype=np.float64), torch.float64)  # a fresh device tensor: updated in place below
         e = ctx.to_dev(eps, torch.float32)
         zd = ctx.to_dev(np.asarray(z, dtype=np.float64), torch.float64)
         _capi.check(ctx.lib.edmp_psample_dev(ctx.h, ptr(X), ptr(e), ptr(zd), b, c, n, int(t), 1), "edmp_psample_dev")
@@ -133,20 +133,22 @@ class Diffusion:
             # guided step.  Device-resident state, one pair of C calls per step.
             if noise is None or isinstance(noise, str):
                 raise ValueError("sharded runs take an explicit noise array (this rank's rows of the global stream)")
-            nd = noise if (isinstance(noise, torch.Tensor) and noise.is_cuda) else ctx.to_dev(noise, torch.float64)
-            X = nd[0].clone()
-            if condition:
-                with torch.cuda.stream(ctx.stream):
+            nd = ctx.adopt(noise) if (isinstance(noise, torch.Tensor) and noise.is_cuda) else ctx.to_dev(noise, torch.float64)
+            with torch.cuda.stream(ctx.stream):  # every torch op on the loop state runs on the context's stream
+                X = nd[0].clone()
+                if condition:
                     X[:, :, 0] = torch.as_tensor(s, device=ctx.device)
                     X[:, :, -1] = torch.as_tensor(g, device=ctx.device)
             for t in range(self.T, int(t_stop), -1):
                 _capi.check(ctx.lib.edmp_step_a_dev(ctx.h, ptr(X), ptr(nd[1 + (self.T - t)]), batch_size, t, _capi.as_pd(s), _capi.as_pd(g),
                                                     1 if zero_row0 else 0, None, None), "edmp_step_a_dev")
                 if guide is not None and (t % 2) < 1 and t >= 5:
-                    ctx.sync()
-                    allreduce(self.sumsq_tensor())
+                    # the collective runs with THIS context's stream current: RCCL orders its own stream after the gradient
+                    # kernels and step_b after the collective, with no host synchronisation (gloo's host copy syncs itself)
+                    with torch.cuda.stream(ctx.stream):
+                        allreduce(self.sumsq_tensor())
                 _capi.check(ctx.lib.edmp_step_b_dev(ctx.h, ptr(X), batch_size, t, _capi.as_pd(s), _capi.as_pd(g), None), "edmp_step_b_dev")
-            return X if return_device else ctx.to_host(X)
+            return ctx.hand_over(X) if return_device else ctx.to_host(X)
         if isinstance(noise, str):
             if noise != "device":
                 raise ValueError("noise must be an array, a device tensor, None (NumPy stream) or 'device'")
@@ -155,7 +157,7 @@ class Diffusion:
                                                     1 if guide is not None else 0, int(t_stop), 1 if zero_row0 else 0, ptr(out)),
                 "edmp_denoise_guided_rng_dev",
             )
-            return out if return_device else ctx.to_host(out)
+            return ctx.hand_over(out) if return_device else ctx.to_host(out)
         if noise is None:
             # Reference contract: z comes from the GLOBAL NumPy RandomState, X_T first, then one draw per step
             # (diffusion.py:303, 126).  The stream is drawn in chunks of `chunk_steps` steps and each chunk is uploaded and
@@ -182,7 +184,7 @@ class Diffusion:
             res = ctx.to_host(out)
             del keep
             return res
-        nd = noise if (isinstance(noise, torch.Tensor) and noise.is_cuda) else ctx.to_dev(noise, torch.float64)
+        nd = ctx.adopt(noise) if (isinstance(noise, torch.Tensor) and noise.is_cuda) else ctx.to_dev(noise, torch.float64)
         if tuple(nd.shape) != (self.T + 1, batch_size, num_channels, traj_len) or nd.dtype != torch.float64:
             raise ValueError(f"noise must be f64 {(self.T + 1, batch_size, num_channels, traj_len)}, got {tuple(nd.shape)} {nd.dtype}")
         _capi.check(
@@ -191,7 +193,7 @@ class Diffusion:
             "edmp_denoise_guided_dev",
         )
         if return_device:
-            return out
+            return ctx.hand_over(out)
         return ctx.to_host(out)
 
     def denoise(self, model, traj_len, num_channels, start=None, goal=None, condition=True, *, batch_size=1, noise=None):
@@ -206,7 +208,7 @@ class Diffusion:
         B, Cc, N = X.shape
         self._prepare(model, guide, B, guidance_schedule)
         _capi.check(ctx.lib.edmp_sampler_set_condition(ctx.h, 1))
-        Xd = ctx.to_dev(np.asarray(X, dtype=np.float64), torch.float64).clone()
+        Xd = ctx.to_dev(np.array(X, dtype=np.float64), torch.float64)  # a fresh device tensor: updated in place below
         zd = ctx.to_dev(np.asarray(z, dtype=np.float64), torch.float64)
         s = np.ascontiguousarray(np.asarray(start, dtype=np.float64).reshape(-1))
         g = np.ascontiguousarray(np.asarray(goal, dtype=np.float64).reshape(-1))
@@ -216,8 +218,8 @@ class Diffusion:
         _capi.check(ctx.lib.edmp_step_a_dev(ctx.h, ptr(Xd), ptr(zd), B, int(t), _capi.as_pd(s), _capi.as_pd(g), 1 if zero_row0 else 0, ptr(eps), ptr(xpost)), "edmp_step_a_dev")
         guided = (t % 2) < 1 and t >= 5
         if guided and allreduce is not None:
-            ctx.sync()
-            allreduce(self.sumsq_tensor())
+            with torch.cuda.stream(ctx.stream):
+                allreduce(self.sumsq_tensor())
         _capi.check(ctx.lib.edmp_step_b_dev(ctx.h, ptr(Xd), B, int(t), _capi.as_pd(s), _capi.as_pd(g), ptr(grad)), "edmp_step_b_dev")
         return dict(eps=ctx.to_host(eps), x_post=ctx.to_host(xpost), grad=ctx.to_host(grad) if guided else None, x_out=ctx.to_host(Xd))
 

@@ -162,7 +162,7 @@ class IntersectionVolumeGuide:
         self._bind()
         ctx = self.ctx
         if isinstance(trajectories, torch.Tensor) and trajectories.is_cuda:
-            X = trajectories.to(torch.float64).contiguous()
+            X = ctx.adopt(trajectories.to(torch.float64).contiguous())
         else:
             X = ctx.to_dev(np.asarray(trajectories, dtype=np.float64), torch.float64)
         B, N = X.shape[0], X.shape[2]

@@ -44,6 +44,8 @@ class Context:
     # ---- helpers ---------------------------------------------------------------------------------------------
     def to_dev(self, arr, dtype) -> torch.Tensor:
         """host ndarray / tensor -> contiguous device tensor on this context's stream."""
+        if isinstance(arr, torch.Tensor) and arr.is_cuda:
+            self.adopt(arr)  # produced on the caller's stream
         with torch.cuda.stream(self.stream):
             if isinstance(arr, torch.Tensor):
                 t = arr.to(device=self.device, dtype=dtype).contiguous()
@@ -54,6 +56,17 @@ class Context:
     def empty(self, shape, dtype) -> torch.Tensor:
         with torch.cuda.stream(self.stream):
             return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def adopt(self, t: torch.Tensor) -> torch.Tensor:
+        """a device tensor produced by the CALLER (on torch's current stream): order this context's stream after it."""
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        return t
+
+    def hand_over(self, t: torch.Tensor) -> torch.Tensor:
+        """a device tensor produced on this context's stream, about to be returned: order torch's current stream after
+        it, so the caller's torch ops on it are safe without an explicit synchronisation."""
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return t
 
     def sync(self):
         _capi.check(self.lib.edmp_ctx_synchronize(self.h), "edmp_ctx_synchronize")

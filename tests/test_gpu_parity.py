@@ -321,6 +321,43 @@ def test_graph_replay_is_bit_identical(golden, tiny_net):
     assert not np.array_equal(got, eager[0])
 
 
+def test_bitwise_determinism_and_stream_handover(golden, tiny_net):
+    """No atomics, no races: repeated UNet forwards (full + ragged batches) and repeated guided loops are bit-identical,
+    and a device tensor returned by denoise_guided(return_device=True) can be used on torch's current stream at once
+    (the context orders the caller's stream after its own)."""
+    from edmp_amd import _capi
+    from edmp_amd.diffusion import Diffusion
+    from edmp_amd.guide import IntersectionVolumeGuide
+    from edmp_amd.runtime import ptr
+    from edmp_amd.temporalunet import TemporalUNet
+
+    net = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, seed=3, max_batch=256)
+    ctx = net.ctx
+    for B in (256, 77, 3):
+        x = ctx.to_dev(torch.randn(B, 7, 50, generator=torch.Generator().manual_seed(B)), torch.float32)
+        eps = ctx.empty(x.shape, torch.float32)
+        ref = None
+        for i in range(40):
+            _capi.check(ctx.lib.edmp_unet_forward_dev(ctx.h, ptr(x), B, 100, ptr(eps)))
+            cur = ctx.hand_over(eps).clone()  # clone runs on torch's current stream
+            ref = cur if ref is None else ref
+            assert torch.equal(cur, ref), (B, i)
+    tiny, _ = tiny_net
+    g = golden("g9_trace_mixed_b12")
+    cfgs = cfgs_for(g["guides"], g["bpg"])
+    B = cfgs["total_batch_size"]
+    guide = IntersectionVolumeGuide(g["scene"], DEV, cfgs, B)
+    dif = Diffusion(T, DEV)
+    noise = torch.from_numpy(noise_for(9, B)).to(DEV)  # made on the caller's stream: the context must adopt it
+    ref = None
+    for i in range(4):
+        X = dif.denoise_guided(tiny, guide, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=g["start"], goal=g["goal"], noise=noise, return_device=True)
+        cur = (X + 0.0).cpu().numpy()  # default-stream op right after the call
+        ref = cur if ref is None else ref
+        assert np.array_equal(cur, ref), i
+    assert np.array_equal(ref, dif.denoise_guided(tiny, guide, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=g["start"], goal=g["goal"], noise=noise_for(9, B)))
+
+
 def test_free_running_unguided(oracle, tiny_net):
     """guide off: the loop is contractive, so 255 free-running steps must track the oracle."""
     from edmp_amd.diffusion import Diffusion
