@@ -405,6 +405,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
 // That is 32..112 MFMAs per wave per barrier instead of 16, and 8x less activation re-reading than the per-position
 // tiling of conv_mfma_kernel.  grid = (8 groups, B/32): blockIdx.x = group, so one XCD's L2 holds one group's weights.
 
+#ifdef EDMP_STAMPS  // phase timing experiment (scratch builds only): one wave of one mid-grid workgroup stamps s_memtime
+__device__ unsigned long long g_stamps[8][16];
+#define EDMP_STAMP(k, i)                                                        \
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == gridDim.y / 2) { \
+        g_stamps[k][2 * (i)] = clock64();                                       \
+        g_stamps[k][2 * (i) + 1] = wall_clock64();                              \
+    }
+#else
+#define EDMP_STAMP(k, i)
+#endif
+
 template <int CG, int L>
 struct RcbCfg {
     static constexpr int KC = 32, LDK = KC + 4;
@@ -439,6 +450,8 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
     constexpr int A_FL = Cf::A_FL, STAGE = Cf::STAGE, NA = Cf::NA, NB = Cf::NB, YS = Cf::YS, NF4 = Cf::NF4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
+    constexpr int SK = (L == 2) ? 2 : (L == 4 && CG == 64) ? 3 : (L == 7) ? 4 : 5;
+    EDMP_STAMP(SK, 0)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -511,6 +524,7 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
     if (nK > 1) EDMP_RCB_FETCH(Q, 1)
     EDMP_RCB_COMMIT(P, lds)
     __syncthreads();
+    EDMP_STAMP(SK, 1)
 
     const int frag = (lane & 31) * LDK + 4 * (lane >> 5);
 
@@ -549,28 +563,121 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
         }                                                                                                      \
     }
 
-    // steady state, unrolled by two so that the register sets alternate statically:
-    //   even step: MFMAs on stage 0 (chunk kk) | set Q (chunk kk+1) lands and is committed to stage 1 | set P fetches chunk kk+2
-    //   odd  step: MFMAs on stage 1 (chunk kk+1) | set P is committed to stage 0 | set Q fetches chunk kk+3
+    // ---- steady state ----------------------------------------------------------------------------------------------
+    // One K step = MFMAs on the current stage + global fetch of the chunk after next + LDS commit of the next chunk.
+    // The three are independent, but one wave per SIMD only overlaps what its own instruction stream interleaves: a
+    // phase-timed build showed fetch + commit + barrier serialised after the MFMAs cost 13-32 % of a step.  So the
+    // first 16 MFMAs of every step (tile 0, first input position - present for every wave) carry the step's memory
+    // instructions in their issue gaps: after each MFMA one or two global loads and one or two ds_writes.
+    // Unrolled by two so that the register sets alternate statically:
+    //   even step: MFMAs on stage 0 (chunk kk)   | set P fetches chunk kk+2 | set Q (chunk kk+1) -> stage 1
+    //   odd  step: MFMAs on stage 1 (chunk kk+1) | set Q fetches chunk kk+3 | set P (chunk kk+2) -> stage 0
+    // Fetches past the last chunk re-read the last chunk and commits of them land in a stage nobody reads again
+    // (unconditional straight-line code is what lets the scheduler interleave).
+#define EDMP_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
+#define EDMP_RCB_MFMA4(t)                                                                  \
+    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[t], 0, 0, 0);           \
+    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[t], 0, 0, 0);           \
+    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[t], 0, 0, 0);           \
+    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[t], 0, 0, 0);
+// memory work of one 4-MFMA group q (0..3): items i with i % 4 == q of the A (<= 7) and B (<= 10) staging lists
+#define EDMP_RCB_MEM0(LS, SS) EDMP_LD_A##LS(0) EDMP_LD_A##LS(4) EDMP_LD_B##LS(0) EDMP_LD_B##LS(4) EDMP_LD_B##LS(8) \
+                              EDMP_ST_A##SS(0) EDMP_ST_A##SS(4) EDMP_ST_B##SS(0) EDMP_ST_B##SS(4) EDMP_ST_B##SS(8)
+#define EDMP_RCB_MEM1(LS, SS) EDMP_LD_A##LS(1) EDMP_LD_A##LS(5) EDMP_LD_B##LS(1) EDMP_LD_B##LS(5) EDMP_LD_B##LS(9) \
+                              EDMP_ST_A##SS(1) EDMP_ST_A##SS(5) EDMP_ST_B##SS(1) EDMP_ST_B##SS(5) EDMP_ST_B##SS(9)
+#define EDMP_RCB_MEM2(LS, SS) EDMP_LD_A##LS(2) EDMP_LD_A##LS(6) EDMP_LD_B##LS(2) EDMP_LD_B##LS(6) \
+                              EDMP_ST_A##SS(2) EDMP_ST_A##SS(6) EDMP_ST_B##SS(2) EDMP_ST_B##SS(6)
+#define EDMP_RCB_MEM3(LS, SS) EDMP_LD_A##LS(3) EDMP_LD_B##LS(3) EDMP_LD_B##LS(7) \
+                              EDMP_ST_A##SS(3) EDMP_ST_B##SS(3) EDMP_ST_B##SS(7)
+#define EDMP_RCB_QMEM(q, LS, SS)                                                                        \
+    {                                                                                                   \
+        const float* an = (q < KC / 8 - 1) ? a_s + 8 * (q + 1) : a_s + (32 * LDK);                      \
+        const float* bn = (q < KC / 8 - 1) ? b_s + 8 * (q + 1) : b_s + (CG * LDK);                      \
+        const float4 a4n = *reinterpret_cast<const float4*>(an);                                        \
+        const float4 b4n = *reinterpret_cast<const float4*>(bn);                                        \
+        EDMP_RCB_MEM##q(LS, SS)                                                                         \
+        EDMP_RCB_MFMA4(0)                                                                               \
+        a4 = a4n;                                                                                       \
+        b4 = b4n;                                                                                       \
+        EDMP_SGB(0x100, 2)                                          /* next fragments */                \
+        EDMP_SGB(0x008, 1) EDMP_SGB(0x020, 2) EDMP_SGB(0x200, 2)    /* MFMA | 2 loads | 2 ds_writes */  \
+        EDMP_SGB(0x008, 1) EDMP_SGB(0x020, 1) EDMP_SGB(0x200, 1)                                        \
+        EDMP_SGB(0x008, 1) EDMP_SGB(0x020, 1) EDMP_SGB(0x200, 1)                                        \
+        EDMP_SGB(0x008, 1) EDMP_SGB(0x020, 1) EDMP_SGB(0x200, 1)                                        \
+    }
+// the remaining input positions of a tile (lp_from .. lp_hi), fragments of the next group requested one group ahead
+#define EDMP_RCB_TAPS(t, lp_from)                                                                              \
+    for (int lp = (lp_from); lp <= lp_hi; ++lp) {                                                              \
+        const int adv = (lp < lp_hi) ? 1 : 0;                                                                  \
+        _Pragma("unroll") for (int q = 0; q < KC / 8; ++q) {                                                   \
+            const float* an = (q < KC / 8 - 1) ? a_s + 8 * (q + 1) : a_s + adv * (32 * LDK);                   \
+            const float* bn = (q < KC / 8 - 1) ? b_s + 8 * (q + 1) : b_s + adv * (CG * LDK);                   \
+            const float4 a4n = *reinterpret_cast<const float4*>(an);                                           \
+            const float4 b4n = *reinterpret_cast<const float4*>(bn);                                           \
+            EDMP_RCB_MFMA4(t)                                                                                  \
+            a4 = a4n;                                                                                          \
+            b4 = b4n;                                                                                          \
+            EDMP_SGB(0x100, 2) /* 2 ds_read (next fragments) ... */                                            \
+            EDMP_SGB(0x008, 4) /* ... ahead of the 4 current MFMAs */                                          \
+        }                                                                                                      \
+        a_s += 32 * LDK;                                                                                       \
+        b_s += CG * LDK;                                                                                       \
+    }
+#define EDMP_RCB_TILE_SETUP(st, j)                                                                             \
+    const int l = (j) / S, s = (j) % S;                                                                        \
+    const int lp_lo = max(0, l - 2), lp_hi = min(L - 1, l + 2);                                                \
+    const float* a_s = (st) + lp_lo * (32 * LDK) + frag;                                                       \
+    const float* b_s = (st) + A_FL + ((lp_lo - l + 2 - KT0) * CG + s * 32) * LDK + frag;                       \
+    float4 a4 = *reinterpret_cast<const float4*>(a_s);                                                         \
+    float4 b4 = *reinterpret_cast<const float4*>(b_s);
+// one K step: MFMAs on stage `st`; register set LS fetches chunk `nc`; register set SS is committed to stage `stn`
+#define EDMP_RCB_STEP(st, LS, nc, SS, stn)                                                                     \
+    {                                                                                                          \
+        const int nc_ = min((nc), nK - 1);                                                                     \
+        const bool first_ = nc_ < ch1;                                                                         \
+        const float* src_ = first_ ? p.src1 : p.src2;                                                          \
+        const int Cs_ = first_ ? p.C1 : p.C2;                                                                  \
+        const int ci0_ = (first_ ? nc_ : nc_ - ch1) * KC;                                                      \
+        const int ag_ = (first_ ? a_g1 : a_g2) + ci0_;                                                         \
+        const int wofs_ = (first_ ? 0 : p.C1) + ci0_;                                                          \
+        float* sn_ = (stn);                                                                                    \
+        {                                                                                                      \
+            EDMP_RCB_TILE_SETUP(st, wave)                                                                      \
+            EDMP_RCB_QMEM(0, LS, SS) EDMP_RCB_QMEM(1, LS, SS) EDMP_RCB_QMEM(2, LS, SS) EDMP_RCB_QMEM(3, LS, SS) \
+            a_s += 32 * LDK;                                                                                   \
+            b_s += CG * LDK;                                                                                   \
+            EDMP_RCB_TAPS(0, lp_lo + 1)                                                                        \
+        }                                                                                                      \
+        _Pragma("unroll") for (int t = 1; t < NT; ++t) {                                                       \
+            const int j = wave + 4 * t;                                                                        \
+            if (j < NTILE) {                                                                                   \
+                EDMP_RCB_TILE_SETUP(st, j)                                                                     \
+                EDMP_RCB_TAPS(t, lp_lo)                                                                        \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+    static_assert(KC == 32 && NTILE >= 4 && L >= 2, "EDMP_RCB_STEP: 4 MFMA groups per position, a tile 0 with >= 2 positions per wave");
     int kk = 0;
     for (; kk + 1 < nK; kk += 2) {
-        if (kk + 2 < nK) EDMP_RCB_FETCH(P, kk + 2)
-        __builtin_amdgcn_sched_barrier(0);
-        EDMP_RCB_COMPUTE(lds)
-        __builtin_amdgcn_sched_barrier(0);
-        EDMP_RCB_COMMIT(Q, lds + STAGE)
+        EDMP_RCB_STEP(lds, P, kk + 2, Q, lds + STAGE)
         __syncthreads();
-        if (kk + 3 < nK) EDMP_RCB_FETCH(Q, kk + 3)
-        __builtin_amdgcn_sched_barrier(0);
-        EDMP_RCB_COMPUTE(lds + STAGE)
-        __builtin_amdgcn_sched_barrier(0);
-        if (kk + 2 < nK) EDMP_RCB_COMMIT(P, lds)
+        EDMP_RCB_STEP(lds + STAGE, Q, kk + 3, P, lds)
         __syncthreads();
     }
     if (kk < nK) {  // odd chunk count: the last chunk sits in stage 0
         EDMP_RCB_COMPUTE(lds)
         __syncthreads();
     }
+#undef EDMP_RCB_STEP
+#undef EDMP_RCB_TILE_SETUP
+#undef EDMP_RCB_TAPS
+#undef EDMP_RCB_QMEM
+#undef EDMP_RCB_MEM0
+#undef EDMP_RCB_MEM1
+#undef EDMP_RCB_MEM2
+#undef EDMP_RCB_MEM3
+#undef EDMP_RCB_MFMA4
+#undef EDMP_SGB
 #undef EDMP_RCB_COMPUTE
 #undef EDMP_RCB_FETCH
 #undef EDMP_RCB_COMMIT
@@ -587,6 +694,7 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
 #undef EDMP_REP7
 #undef EDMP_REP10
     __syncthreads();
+    EDMP_STAMP(SK, 2)
 
     // ---- epilogue: raw tile (+bias) -> LDS, per-sample statistics over the whole group, normalise, Mish, add, store
     float* Y = lds;  // [32][YS]; all MFMA reads of the stages are complete (barrier above)
@@ -626,6 +734,7 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
         }
     }
     __syncthreads();
+    EDMP_STAMP(SK, 3)
     {
         const int row = erow, part = epart;
         const int b = b0 + row;
@@ -669,6 +778,7 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
             }
         }
     }
+    EDMP_STAMP(SK, 4)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -713,6 +823,8 @@ __global__ __launch_bounds__(256) void rcb_rows_kernel(RcbP p) {
     static_assert(NA <= 4 && NB <= 10 && TPW <= 2, "staging macros cover NA <= 4, NB <= 10, two tiles per wave");
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
+    constexpr int SK = (L == 13) ? 0 : (L == 7) ? 1 : 6;
+    EDMP_STAMP(SK, 0)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -790,6 +902,7 @@ __global__ __launch_bounds__(256) void rcb_rows_kernel(RcbP p) {
     EDMP_ROWS_FETCH(0)
     EDMP_ROWS_COMMIT(lds)
     __syncthreads();
+    EDMP_STAMP(SK, 1)
 
 #define EDMP_ROWS_TILE(st, accv, arow, brow)                                                          \
     _Pragma("unroll") for (int k = 0; k < 5; ++k) {                                                    \
@@ -835,6 +948,7 @@ __global__ __launch_bounds__(256) void rcb_rows_kernel(RcbP p) {
 #undef EDMP_DECL_XB
 #undef EDMP_REP4
 #undef EDMP_REP10
+    EDMP_STAMP(SK, 2)
 
     // ---- epilogue: raw (+bias) -> LDS Y[row][channel]; per (sample, group) statistics; normalise, Mish, add, store
     float* Y = lds;
@@ -887,6 +1001,7 @@ __global__ __launch_bounds__(256) void rcb_rows_kernel(RcbP p) {
         }
     }
     __syncthreads();
+    EDMP_STAMP(SK, 3)
     {
         // 16 lanes per (sample, group) unit, two-pass statistics
         const int l16 = tid & 15;
@@ -918,6 +1033,7 @@ __global__ __launch_bounds__(256) void rcb_rows_kernel(RcbP p) {
         }
     }
     __syncthreads();
+    EDMP_STAMP(SK, 4)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int f = tid + it * 256;
@@ -939,6 +1055,7 @@ __global__ __launch_bounds__(256) void rcb_rows_kernel(RcbP p) {
             }
         }
     }
+    EDMP_STAMP(SK, 5)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2180,3 +2297,9 @@ extern "C" int edmp_unet_flops(edmp_ctx* ctx, double* nominal, double* executed)
     if (executed) *executed = ctx->unet->flops_exec;
     return EDMP_OK;
 }
+
+#ifdef EDMP_STAMPS
+extern "C" int edmp_debug_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(edmp::g_stamps), sizeof(unsigned long long) * 8 * 16);
+}
+#endif
