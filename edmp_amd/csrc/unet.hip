@@ -518,6 +518,11 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    // the conv bias of this wave's tiles is requested NOW: loaded where it is used (first thing of the epilogue) it would
+    // sit behind the epilogue's own operand prefetches in the in-order vmcnt queue and stall the accumulator spill ~1 us
+    static_assert(NT <= 2, "bias registers cover two tiles per wave");
+    const float bias_t0 = p.bias[co0 + (wave % S) * 32 + (lane & 31)];
+    const float bias_t1 = p.bias[co0 + (min(wave + 4, NTILE - 1) % S) * 32 + (lane & 31)];
 
     // prologue: chunk 0 -> stage 0, chunk 1 in flight in set Q
     EDMP_RCB_FETCH(P, 0)
@@ -709,15 +714,11 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
         const int l = col / CG, ch = co0 + col % CG;
         g4[i] = *reinterpret_cast<const float4*>(p.gamma + ch);
         be4[i] = *reinterpret_cast<const float4*>(p.beta + ch);
+        // exactly one addend per launch (conv1: time bias, conv2: residual; checked by the launcher).  Summing two
+        // loads here would put an s_waitcnt vmcnt(0) - a full memory round trip - into every iteration of this loop
         ad4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.add_tb) ad4[i] = *reinterpret_cast<const float4*>(p.add_tb + ch);
-        if (p.add_res) {
-            const float4 rr = *reinterpret_cast<const float4*>(p.add_res + ((size_t)eb * L + l) * p.Cout + ch);
-            ad4[i].x += rr.x;
-            ad4[i].y += rr.y;
-            ad4[i].z += rr.z;
-            ad4[i].w += rr.w;
-        }
+        if (p.add_res) ad4[i] = *reinterpret_cast<const float4*>(p.add_res + ((size_t)eb * L + l) * p.Cout + ch);
+        else if (p.add_tb) ad4[i] = *reinterpret_cast<const float4*>(p.add_tb + ch);
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
         if (j < NTILE) {
             const int l = j / S, s = j % S;
             const int cc = s * 32 + (lane & 31);
-            const float bias = p.bias[co0 + cc];
+            const float bias = (t == 0) ? bias_t0 : bias_t1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -890,6 +891,9 @@ __global__ __launch_bounds__(256) void rcb_rows_kernel(RcbP p) {
     // this wave's tiles: j = wave + 4*t -> (row tile mt, channel tile nt)
     const int j0 = wave, j1 = wave + 4;
     const bool has0 = j0 < NTILE, has1 = (TPW > 1) && (j1 < NTILE);
+    // conv bias of this wave's tiles, requested up front (see rcb_conv_kernel)
+    const float bias_t0 = p.bias[co0 + (min(j0, NTILE - 1) % NT) * 32 + (lane & 31)];
+    const float bias_t1 = p.bias[co0 + (min(j1, NTILE - 1) % NT) * 32 + (lane & 31)];
     const int fr = 4 * (lane >> 5);
     const int r0 = min((j0 / NT) * 32 + (lane & 31), ROWS - 1);
     const int r1 = min((j1 / NT) * 32 + (lane & 31), ROWS - 1);
@@ -969,21 +973,15 @@ __global__ __launch_bounds__(256) void rcb_rows_kernel(RcbP p) {
         const int bb = min(b0 + r / L, p.B - 1);
         g4[it] = *reinterpret_cast<const float4*>(p.gamma + ch);
         be4[it] = *reinterpret_cast<const float4*>(p.beta + ch);
-        ad4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.add_tb) ad4[it] = *reinterpret_cast<const float4*>(p.add_tb + ch);
-        if (p.add_res) {
-            const float4 rr = *reinterpret_cast<const float4*>(p.add_res + ((size_t)bb * L + r % L) * p.Cout + ch);
-            ad4[it].x += rr.x;
-            ad4[it].y += rr.y;
-            ad4[it].z += rr.z;
-            ad4[it].w += rr.w;
-        }
+        ad4[it] = make_float4(0.f, 0.f, 0.f, 0.f);  // one addend per launch (see rcb_conv_kernel)
+        if (p.add_res) ad4[it] = *reinterpret_cast<const float4*>(p.add_res + ((size_t)bb * L + r % L) * p.Cout + ch);
+        else if (p.add_tb) ad4[it] = *reinterpret_cast<const float4*>(p.add_tb + ch);
     }
     {
         const int cc = lane & 31;
         if (has0) {
             const int mt = j0 / NT, nt = j0 % NT;
-            const float bias = p.bias[co0 + nt * 32 + cc];
+            const float bias = bias_t0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -992,7 +990,7 @@ __global__ __launch_bounds__(256) void rcb_rows_kernel(RcbP p) {
         }
         if (has1) {
             const int mt = j1 / NT, nt = j1 % NT;
-            const float bias = p.bias[co0 + nt * 32 + cc];
+            const float bias = bias_t1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -1165,6 +1163,9 @@ __global__ __launch_bounds__(256) void rcb_block_kernel(BlkP p) {
     }
     const int j0 = wave, j1 = wave + 4;
     const bool has0 = j0 < NTILE, has1 = (TPW > 1) && (j1 < NTILE);
+    // both convs' biases of this wave's tiles, requested up front (see rcb_conv_kernel)
+    const float b1_t0 = p.b1[(min(j0, NTILE - 1) % NT) * 32 + (lane & 31)], b1_t1 = p.b1[(min(j1, NTILE - 1) % NT) * 32 + (lane & 31)];
+    const float b2_t0 = p.b2[(min(j0, NTILE - 1) % NT) * 32 + (lane & 31)], b2_t1 = p.b2[(min(j1, NTILE - 1) % NT) * 32 + (lane & 31)];
     const int fr = 4 * (lane >> 5);
     const int r0 = min((j0 / NT) * 32 + (lane & 31), ROWS - 1);
     const int r1 = min((j1 / NT) * 32 + (lane & 31), ROWS - 1);
@@ -1257,13 +1258,13 @@ __global__ __launch_bounds__(256) void rcb_block_kernel(BlkP p) {
         const int cc = lane & 31;
         if (has0) {
             const int mt = j0 / NT, nt = j0 % NT;
-            const float bias = p.b1[nt * 32 + cc];
+            const float bias = b1_t0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) Y[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * YS + nt * 32 + cc] = acc0[r] + bias;
         }
         if (has1) {
             const int mt = j1 / NT, nt = j1 % NT;
-            const float bias = p.b1[nt * 32 + cc];
+            const float bias = b1_t1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) Y[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * YS + nt * 32 + cc] = acc1[r] + bias;
         }
@@ -1368,7 +1369,7 @@ __global__ __launch_bounds__(256) void rcb_block_kernel(BlkP p) {
         const int cc = lane & 31;
         if (has0) {
             const int mt = j0 / NT, nt = j0 % NT;
-            const float bias = p.b2[nt * 32 + cc];
+            const float bias = b2_t0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc0[r] += bias;
@@ -1377,7 +1378,7 @@ __global__ __launch_bounds__(256) void rcb_block_kernel(BlkP p) {
         }
         if (has1) {
             const int mt = j1 / NT, nt = j1 % NT;
-            const float bias = p.b2[nt * 32 + cc];
+            const float bias = b2_t1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc1[r] += bias;
@@ -2202,6 +2203,7 @@ int unet_run_program(edmp_ctx* ctx, int B, int t) {
             RcbP p = op.rc;
             p.B = B;
             p.add_tb = op.tb_off >= 0 ? trow + op.tb_off : nullptr;
+            EDMP_REQUIRE(!(p.add_tb && p.add_res), "fused conv block: a launch adds the time bias (conv1) or the residual (conv2), not both");
             std::pair<hipEvent_t, hipEvent_t> ev{};
             if (pf.on) {
                 if (!pf.pool.empty()) {
