@@ -789,6 +789,56 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
 // and reads the 5 tap-shifted A operands of Conv1d(k=5, pad=2) straight out of that tile (row + tap) — no im2col, no
 // per-tap reload — against the [5][CB][KC] weight slab.  Statistics are complete in the workgroup; the raw conv output
 // never reaches HBM.  grid = (Cout/CB, B/SB).
+// Per (sample, group) GroupNorm statistics of a raw conv tile Y[row = sample*L + position][YS] held in LDS: unit u =
+// (sample b, group g of 2^cgs channels), 16 lanes per unit, 16 units per pass over the workgroup.  Each lane reads its
+// share ONCE as float4 (4 consecutive channels of one position; 2^cgs >= 4) and keeps it in registers for the second,
+// centred pass (two-pass variance like torch's group_norm).  Writes stat[2*(b*16+g)] = mean, [...+1] = 1/sqrt(var+eps).
+template <int L>
+__device__ __forceinline__ void group_stats_lds(const float* __restrict__ Y, int YS, float* __restrict__ stat, int units, int G, int cgs,
+                                                int tid) {
+    constexpr int NE4 = (L + 3) / 4;  // float4 per lane at the widest group (16 channels): ceil(L*16/4/16)
+    const int l16 = tid & 15;
+    const int cgm = (1 << cgs) - 1;
+    const int n4 = (L << cgs) >> 2;
+    const float inv_n = 1.0f / (float)(L << cgs);
+    for (int u = tid >> 4; u < units; u += 16) {
+        const int b = u / G, g = u - b * G;
+        const float* yb = Y + (b * L) * YS + (g << cgs);
+        float4 v[NE4];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NE4; ++i) {
+            const int e = 4 * (l16 + 16 * i);
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (l16 + 16 * i < n4) {
+                v[i] = *reinterpret_cast<const float4*>(yb + (e >> cgs) * YS + (e & cgm));
+                sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            }
+        }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        sum += __shfl_xor(sum, 4, 64);
+        sum += __shfl_xor(sum, 8, 64);
+        const float mean = sum * inv_n;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NE4; ++i) {
+            if (l16 + 16 * i < n4) {
+                const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+                sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+        }
+        sq += __shfl_xor(sq, 1, 64);
+        sq += __shfl_xor(sq, 2, 64);
+        sq += __shfl_xor(sq, 4, 64);
+        sq += __shfl_xor(sq, 8, 64);
+        if (l16 == 0) {
+            stat[2 * (b * 16 + g)] = mean;
+            stat[2 * (b * 16 + g) + 1] = 1.0f / sqrtf(sq * inv_n + 1e-5f);
+        }
+    }
+}
+
 template <int CB, int L, int SB, int KC>
 struct RowsCfg {
     static constexpr int LDK = KC + 4;
@@ -1000,36 +1050,7 @@ __global__ __launch_bounds__(256) void rcb_rows_kernel(RcbP p) {
     }
     __syncthreads();
     EDMP_STAMP(SK, 3)
-    {
-        // 16 lanes per (sample, group) unit, two-pass statistics
-        const int l16 = tid & 15;
-        const int n = L << cgs;
-        const float inv_n = 1.0f / (float)n;
-        for (int u = tid >> 4; u < SB * G; u += 16) {
-            const int b = u / G, g = u - b * G;
-            const float* yb = Y + (b * L) * YS + (g << cgs);
-            float sum = 0.f;
-            for (int e = l16; e < n; e += 16) sum += yb[(e >> cgs) * YS + (e & (cg - 1))];
-            sum += __shfl_xor(sum, 1, 64);
-            sum += __shfl_xor(sum, 2, 64);
-            sum += __shfl_xor(sum, 4, 64);
-            sum += __shfl_xor(sum, 8, 64);
-            const float mean = sum * inv_n;
-            float sq = 0.f;
-            for (int e = l16; e < n; e += 16) {
-                const float d = yb[(e >> cgs) * YS + (e & (cg - 1))] - mean;
-                sq += d * d;
-            }
-            sq += __shfl_xor(sq, 1, 64);
-            sq += __shfl_xor(sq, 2, 64);
-            sq += __shfl_xor(sq, 4, 64);
-            sq += __shfl_xor(sq, 8, 64);
-            if (l16 == 0) {
-                stat[2 * (b * 16 + g)] = mean;
-                stat[2 * (b * 16 + g) + 1] = 1.0f / sqrtf(sq * inv_n + 1e-5f);
-            }
-        }
-    }
+    group_stats_lds<L>(Y, YS, stat, SB * G, G, cgs, tid);
     __syncthreads();
     EDMP_STAMP(SK, 4)
 #pragma unroll
@@ -1271,36 +1292,7 @@ __global__ __launch_bounds__(256) void rcb_block_kernel(BlkP p) {
     }
     __syncthreads();
 // per (sample, group) mean / rstd of the Y tile, 16 lanes per unit, two-pass
-#define EDMP_BLK_STATS()                                                                   \
-    {                                                                                      \
-        const int l16 = tid & 15;                                                          \
-        constexpr int n_ = L * CG;                                                         \
-        constexpr float inv_n = 1.0f / (float)n_;                                          \
-        for (int u = tid >> 4; u < SB * G; u += 16) {                                      \
-            const int b = u / G, g = u - b * G;                                            \
-            const float* yb = Y + (b * L) * YS + g * CG;                                   \
-            float sum = 0.f;                                                               \
-            for (int e = l16; e < n_; e += 16) sum += yb[(e >> CGS) * YS + (e & (CG - 1))]; \
-            sum += __shfl_xor(sum, 1, 64);                                                 \
-            sum += __shfl_xor(sum, 2, 64);                                                 \
-            sum += __shfl_xor(sum, 4, 64);                                                 \
-            sum += __shfl_xor(sum, 8, 64);                                                 \
-            const float mean = sum * inv_n;                                                \
-            float sq = 0.f;                                                                \
-            for (int e = l16; e < n_; e += 16) {                                           \
-                const float d = yb[(e >> CGS) * YS + (e & (CG - 1))] - mean;               \
-                sq += d * d;                                                               \
-            }                                                                              \
-            sq += __shfl_xor(sq, 1, 64);                                                   \
-            sq += __shfl_xor(sq, 2, 64);                                                   \
-            sq += __shfl_xor(sq, 4, 64);                                                   \
-            sq += __shfl_xor(sq, 8, 64);                                                   \
-            if (l16 == 0) {                                                                \
-                stat[2 * (b * 16 + g)] = mean;                                             \
-                stat[2 * (b * 16 + g) + 1] = 1.0f / sqrtf(sq * inv_n + 1e-5f);             \
-            }                                                                              \
-        }                                                                                  \
-    }
+#define EDMP_BLK_STATS() group_stats_lds<L>(Y, YS, stat, SB * G, G, CGS, tid);
     EDMP_BLK_STATS()
     __syncthreads();
     for (int f = tid; f < ROWS * (C / 4); f += 256) {
