@@ -1125,6 +1125,9 @@ __global__ __launch_bounds__(256) void rcb_block_kernel(BlkP p) {
     const int Cin = p.C1 + p.C2;
     const int ch1 = p.C1 / KC1, ch2 = p.C2 / KC1;
     const int nK1 = ch1 + ch2;
+    // stamps: one variant only
+#define EDMP_BSTAMP(i) if constexpr (C == 64 && L == 25 && !RES) { EDMP_STAMP(7, i) }
+    EDMP_BSTAMP(0)
 
     for (int i = tid; i < H_FL / 4; i += 256) *reinterpret_cast<float4*>(H + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < A1_FL / 4; i += 256) {
@@ -1187,6 +1190,18 @@ __global__ __launch_bounds__(256) void rcb_block_kernel(BlkP p) {
     // both convs' biases of this wave's tiles, requested up front (see rcb_conv_kernel)
     const float b1_t0 = p.b1[(min(j0, NTILE - 1) % NT) * 32 + (lane & 31)], b1_t1 = p.b1[(min(j1, NTILE - 1) % NT) * 32 + (lane & 31)];
     const float b2_t0 = p.b2[(min(j0, NTILE - 1) % NT) * 32 + (lane & 31)], b2_t1 = p.b2[(min(j1, NTILE - 1) % NT) * 32 + (lane & 31)];
+    float br_t0 = 0.f, br_t1 = 0.f;
+    if constexpr (RES) {
+        br_t0 = p.br[(min(j0, NTILE - 1) % NT) * 32 + (lane & 31)];
+        br_t1 = p.br[(min(j1, NTILE - 1) % NT) * 32 + (lane & 31)];
+    }
+    // both epilogues' final passes walk the tile as float4 with stride 256 threads, and 256 % (C/4) == 0: a thread always
+    // handles the same four channels `ecc`, so its affine parameters and time bias are loaded once, here, long before use
+    static_assert(256 % (C / 4) == 0, "a thread keeps its channel quad across the epilogue passes");
+    const int ecc = (tid % (C / 4)) * 4;
+    const float4 g1v = *reinterpret_cast<const float4*>(p.g1 + ecc), be1v = *reinterpret_cast<const float4*>(p.be1 + ecc);
+    const float4 tbv = *reinterpret_cast<const float4*>(p.tb + ecc);
+    const float4 g2v = *reinterpret_cast<const float4*>(p.g2 + ecc), be2v = *reinterpret_cast<const float4*>(p.be2 + ecc);
     const int fr = 4 * (lane >> 5);
     const int r0 = min((j0 / NT) * 32 + (lane & 31), ROWS - 1);
     const int r1 = min((j1 / NT) * 32 + (lane & 31), ROWS - 1);
@@ -1197,6 +1212,7 @@ __global__ __launch_bounds__(256) void rcb_block_kernel(BlkP p) {
     EDMP_BLK_FETCH1(0)
     EDMP_BLK_COMMIT1(work)
     __syncthreads();
+    EDMP_BSTAMP(1)
 
 // conv1 taps (+ the residual slab at the centre tap) of one K chunk for one 32x32 tile
 #define EDMP_BLK_TILE1(st, accv, racv, xr, bcol)                                                      \
@@ -1233,6 +1249,7 @@ __global__ __launch_bounds__(256) void rcb_block_kernel(BlkP p) {
         __syncthreads();
     }
     EDMP_BLK_COMPUTE1(work + ((nK1 - 1) & 1) * STAGE1)
+    EDMP_BSTAMP(2)
 #undef EDMP_BLK_COMPUTE1
 #undef EDMP_BLK_TILE1
 #undef EDMP_BLK_FETCH1
@@ -1301,9 +1318,7 @@ __global__ __launch_bounds__(256) void rcb_block_kernel(BlkP p) {
         const int g = cc >> CGS;
         const float mean = stat[2 * (b * 16 + g)], rstd = stat[2 * (b * 16 + g) + 1];
         const float4 v = *reinterpret_cast<const float4*>(Y + r * YS + cc);
-        const float4 g4 = *reinterpret_cast<const float4*>(p.g1 + cc);
-        const float4 be4 = *reinterpret_cast<const float4*>(p.be1 + cc);
-        const float4 tb4 = *reinterpret_cast<const float4*>(p.tb + cc);
+        const float4 g4 = g1v, be4 = be1v, tb4 = tbv;  // cc == ecc
         float4 o;
         const float s0 = rstd * g4.x, s1 = rstd * g4.y, s2 = rstd * g4.z, s3 = rstd * g4.w;
         o.x = mish_fast(v.x * s0 + (be4.x - s0 * mean)) + tb4.x;
@@ -1313,6 +1328,7 @@ __global__ __launch_bounds__(256) void rcb_block_kernel(BlkP p) {
         *reinterpret_cast<float4*>(H + (b * (L + 4) + l + 2) * HS + cc) = o;
     }
     __syncthreads();  // H complete, Y dead
+    EDMP_BSTAMP(3)
 
     // ---- phase 2: conv2 over the C channels of H (A operand straight from the H tile), weights streamed per 32-channel chunk
 #pragma unroll
@@ -1356,56 +1372,76 @@ __global__ __launch_bounds__(256) void rcb_block_kernel(BlkP p) {
 #undef EDMP_REP4
 #undef EDMP_REP12
 
-    // ---- epilogue 2: statistics of conv2 + b2 via LDS, then out = Mish(GN(.)) + residual applied in the accumulator layout
+    EDMP_BSTAMP(4)
+    // ---- epilogue 2: conv2 + b2 (and the residual conv + br) -> LDS, statistics, then one coalesced float4 pass:
+    //      out = Mish(GN(conv2)) + residual.  The identity residual (the block input) is requested from global memory first,
+    //      so it lands under the spill + statistics; the residual-conv tile reuses the dead H tile.
+    constexpr int NIT = (ROWS * (C / 4) + 255) / 256;
+    float4 res4[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        res4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (!RES) {
+            const int r = min(tid + it * 256, ROWS * (C / 4) - 1) / (C / 4);
+            const int bb = min(b0 + r / L, p.B - 1);
+            res4[it] = *reinterpret_cast<const float4*>(p.src1 + ((size_t)bb * L + r % L) * C + ecc);
+        }
+    }
+    float* R = H;  // [ROWS][YS] residual-conv tile (RES); every wave left the conv2 loop through its closing barrier
+    static_assert(ROWS * YS <= H_FL, "the residual tile fits in the H tile");
     {
         const int cc = lane & 31;
         if (has0) {
             const int mt = j0 / NT, nt = j0 % NT;
-            const float bias = b2_t0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                acc0[r] += bias;
-                Y[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * YS + nt * 32 + cc] = acc0[r];
+                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                Y[row * YS + nt * 32 + cc] = acc0[r] + b2_t0;
+                if constexpr (RES)
+                    if (row < ROWS) R[row * YS + nt * 32 + cc] = rac0[r] + br_t0;
             }
         }
         if (has1) {
             const int mt = j1 / NT, nt = j1 % NT;
-            const float bias = b2_t1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                acc1[r] += bias;
-                Y[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * YS + nt * 32 + cc] = acc1[r];
+                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                Y[row * YS + nt * 32 + cc] = acc1[r] + b2_t1;
+                if constexpr (RES)
+                    if (row < ROWS) R[row * YS + nt * 32 + cc] = rac1[r] + br_t1;
             }
         }
     }
     __syncthreads();
+    EDMP_BSTAMP(5)
     EDMP_BLK_STATS()
 #undef EDMP_BLK_STATS
     __syncthreads();
-#define EDMP_BLK_OUT(accv, racv, jj)                                                                         \
-    {                                                                                                        \
-        const int mt = (jj) / NT, nt = (jj) % NT;                                                            \
-        const int ch = nt * 32 + (lane & 31);                                                                \
-        const int g = ch >> CGS;                                                                             \
-        const float gam = p.g2[ch], bet = p.be2[ch];                                                         \
-        const float rbias = RES ? p.br[ch] : 0.0f;                                                           \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                     \
-            const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);                              \
-            if (row < ROWS) {                                                                                \
-                const int b = row / L, l = row % L;                                                          \
-                if (b0 + b < p.B) {                                                                          \
-                    const float mean = stat[2 * (b * 16 + g)], rstd = stat[2 * (b * 16 + g) + 1];            \
-                    const float sc = rstd * gam;                                                             \
-                    const size_t go = ((size_t)(b0 + b) * L + l) * C + ch;                                   \
-                    const float res = RES ? (racv[r] + rbias) : p.src1[go];                                  \
-                    p.dst[go] = mish_fast(accv[r] * sc + (bet - sc * mean)) + res;                           \
-                }                                                                                            \
-            }                                                                                                \
-        }                                                                                                    \
+    EDMP_BSTAMP(6)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int f = tid + it * 256;
+        if (f < ROWS * (C / 4)) {
+            const int r = f / (C / 4);
+            const int b = r / L, l = r % L;
+            if (b0 + b < p.B) {
+                const int g = ecc >> CGS;
+                const float mean = stat[2 * (b * 16 + g)], rstd = stat[2 * (b * 16 + g) + 1];
+                const float4 v = *reinterpret_cast<const float4*>(Y + r * YS + ecc);
+                float4 rs = res4[it];
+                if constexpr (RES) rs = *reinterpret_cast<const float4*>(R + r * YS + ecc);
+                const float s0 = rstd * g2v.x, s1 = rstd * g2v.y, s2 = rstd * g2v.z, s3 = rstd * g2v.w;
+                float4 o;
+                o.x = mish_fast(v.x * s0 + (be2v.x - s0 * mean)) + rs.x;
+                o.y = mish_fast(v.y * s1 + (be2v.y - s1 * mean)) + rs.y;
+                o.z = mish_fast(v.z * s2 + (be2v.z - s2 * mean)) + rs.z;
+                o.w = mish_fast(v.w * s3 + (be2v.w - s3 * mean)) + rs.w;
+                *reinterpret_cast<float4*>(p.dst + ((size_t)(b0 + b) * L + l) * C + ecc) = o;
+            }
+        }
     }
-    if (has0) EDMP_BLK_OUT(acc0, rac0, j0)
-    if (has1) EDMP_BLK_OUT(acc1, rac1, j1)
-#undef EDMP_BLK_OUT
+    EDMP_BSTAMP(7)
+#undef EDMP_BSTAMP
 }
 
 // GroupNorm(8 groups, eps 1e-5, biased variance) -> Mish -> (+ time bias[c] | + residual[b,l,c]) in place.
