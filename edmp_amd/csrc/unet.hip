@@ -329,6 +329,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    // requested now, used by the store epilogue: loaded there it would expose a full memory round trip
+    const float bias_v = p.bias[min(n0 + wn * 32 + (lane & 31), p.Cout - 1)];
 
     const int arow = (wm * 32 + (lane & 31)) * LDK + 4 * (lane >> 5);
     const int brow = BM * LDK + (wn * 32 + (lane & 31)) * LDK + 4 * (lane >> 5);
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
     // epilogue: + bias, store [b][lo][co].  acc[r]: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
     const int co = n0 + wn * 32 + (lane & 31);
     if (co < p.Cout) {
-        const float bias = p.bias[co];
+        const float bias = bias_v;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);

@@ -16,7 +16,7 @@ net = TemporalUNet(None, 7, 32, "cuda:0", dims=(32, 64, 128, 256, 512, 512), see
 ctx = net.ctx
 x = ctx.to_dev(torch.randn(B, 7, 50), torch.float32)
 eps = ctx.empty(x.shape, torch.float32)
-for _ in range(3):
+for _ in range(int(os.environ.get("EDMP_PMC_FORWARDS", "3"))):
     _capi.check(ctx.lib.edmp_unet_forward_dev(ctx.h, ptr(x), B, 100, ptr(eps)))
 ctx.sync()
 print("done")
