@@ -148,6 +148,10 @@ struct RcbP {
     float* dst;            // [B][L][Cout]
     int Cout;
     int B;
+    // folded residual 1x1 conv of the block input (rcb_conv_kernel<.,.,true>): its weights [Cout][Cin] sit right behind
+    // the five conv taps in W (tap index 5); res_out [B][L][Cout] receives conv + res_bias for conv2's epilogue
+    float* res_out;
+    const float* res_bias;
 };
 
 struct BlkP {
@@ -418,7 +422,7 @@ __device__ unsigned long long g_stamps[8][16];
 #define EDMP_STAMP(k, i)
 #endif
 
-template <int CG, int L>
+template <int CG, int L, bool RES = false>
 struct RcbCfg {
     static constexpr int KC = 32, LDK = KC + 4;
     static constexpr int S = CG / 32;
@@ -426,11 +430,12 @@ struct RcbCfg {
     static constexpr int NT = (NTILE + 3) / 4;
     static constexpr int KT0 = (L == 2) ? 1 : 0;
     static constexpr int NTAP = (L == 2) ? 3 : 5;
+    static constexpr int NSLAB = NTAP + (RES ? 1 : 0);  // weight slabs per K step: the valid taps (+ the residual 1x1 conv)
     static constexpr int A_FL = L * 32 * LDK;
-    static constexpr int B_FL = NTAP * CG * LDK;
+    static constexpr int B_FL = NSLAB * CG * LDK;
     static constexpr int STAGE = A_FL + B_FL;
     static constexpr int NA = L;
-    static constexpr int NB = NTAP * CG / 32;
+    static constexpr int NB = NSLAB * CG / 32;
     static constexpr int YS = L * CG + 4;
     static constexpr int NF4 = L * CG / 32;  // float4 per thread in the epilogue
     static constexpr size_t lds_bytes() {
@@ -445,10 +450,10 @@ struct RcbCfg {
     }
 };
 
-template <int CG, int L>
+template <int CG, int L, bool RES>
 __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
-    using Cf = RcbCfg<CG, L>;
-    constexpr int KC = Cf::KC, LDK = Cf::LDK, S = Cf::S, NTILE = Cf::NTILE, NT = Cf::NT, KT0 = Cf::KT0;
+    using Cf = RcbCfg<CG, L, RES>;
+    constexpr int KC = Cf::KC, LDK = Cf::LDK, S = Cf::S, NTILE = Cf::NTILE, NT = Cf::NT, KT0 = Cf::KT0, NTAP = Cf::NTAP;
     constexpr int A_FL = Cf::A_FL, STAGE = Cf::STAGE, NA = Cf::NA, NB = Cf::NB, YS = Cf::YS, NF4 = Cf::NF4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -472,10 +477,12 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
     // staging registers are individual scalars: hipcc parks small arrays in scratch memory once scheduling
     // barriers pin the prefetch (seen with ROCm 7.2), which would serialise every load behind a vmcnt(0)
 #define EDMP_REP7(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6)
-#define EDMP_REP10(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9)
-    static_assert(NA <= 7 && NB <= 10, "staging macros cover NA <= 7, NB <= 10");
+#define EDMP_REP10(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
+    static_assert(NA <= 7 && NB <= 12, "staging macros cover NA <= 7, NB <= 12");
+    // weight slab of staging item i: slabs 0..NTAP-1 are the conv taps KT0.., slab NTAP (RES) is the residual 1x1 conv,
+    // stored as tap index 5 of the packed weight tensor
 #define EDMP_DECL_RB(i)                                                                              \
-    const int wg##i = ((KT0 + (tid + i * 256) / (CG * 8)) * p.Cout + co0 + (((tid + i * 256) % (CG * 8)) >> 3)) * Cin + sc4; \
+    const int wg##i = ((((tid + i * 256) / (CG * 8)) < NTAP ? KT0 + (tid + i * 256) / (CG * 8) : 5) * p.Cout + co0 + (((tid + i * 256) % (CG * 8)) >> 3)) * Cin + sc4; \
     const int bl##i = A_FL + (((tid + i * 256) / (CG * 8)) * CG + (((tid + i * 256) % (CG * 8)) >> 3)) * LDK + sc4;          \
     float4 rbP##i = make_float4(0.f, 0.f, 0.f, 0.f), rbQ##i = make_float4(0.f, 0.f, 0.f, 0.f);
 #define EDMP_DECL_RA(i) float4 raP##i = make_float4(0.f, 0.f, 0.f, 0.f), raQ##i = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -525,6 +532,17 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
     static_assert(NT <= 2, "bias registers cover two tiles per wave");
     const float bias_t0 = p.bias[co0 + (wave % S) * 32 + (lane & 31)];
     const float bias_t1 = p.bias[co0 + (min(wave + 4, NTILE - 1) % S) * 32 + (lane & 31)];
+    // folded residual 1x1 conv (RES): a second accumulator per tile, fed by the centre input position against weight slab NTAP
+    f32x16 racc[RES ? NT : 1];
+    float rbias_t0 = 0.f, rbias_t1 = 0.f;
+    if constexpr (RES) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) racc[t][i] = 0.0f;
+        rbias_t0 = p.res_bias[co0 + (wave % S) * 32 + (lane & 31)];
+        rbias_t1 = p.res_bias[co0 + (min(wave + 4, NTILE - 1) % S) * 32 + (lane & 31)];
+    }
 
     // prologue: chunk 0 -> stage 0, chunk 1 in flight in set Q
     EDMP_RCB_FETCH(P, 0)
@@ -535,6 +553,20 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
 
     const int frag = (lane & 31) * LDK + 4 * (lane >> 5);
 
+// the residual 1x1 conv of tile (l, s): centre position l of the A stage x weight slab NTAP, 16 MFMAs into racc[t]
+#define EDMP_RCB_RESID(st, t, l, s)                                                                            \
+    if constexpr (RES) {                                                                                       \
+        const float* ar_ = (st) + (l) * (32 * LDK) + frag;                                                     \
+        const float* br_ = (st) + A_FL + (NTAP * CG + (s) * 32) * LDK + frag;                                  \
+        _Pragma("unroll") for (int q = 0; q < KC / 8; ++q) {                                                   \
+            const float4 ra4 = *reinterpret_cast<const float4*>(ar_ + 8 * q);                                 \
+            const float4 rb4 = *reinterpret_cast<const float4*>(br_ + 8 * q);                                 \
+            racc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra4.x, rb4.x, racc[t], 0, 0, 0);                    \
+            racc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra4.y, rb4.y, racc[t], 0, 0, 0);                    \
+            racc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra4.z, rb4.z, racc[t], 0, 0, 0);                    \
+            racc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra4.w, rb4.w, racc[t], 0, 0, 0);                    \
+        }                                                                                                      \
+    }
 // all MFMAs of one K step for this wave's tiles, reading stage `st`.  The A/B fragments of the NEXT group of four
 // MFMAs are requested from LDS before the current four are issued (software pipelining by hand: one wave per SIMD
 // has nobody else to hide the ds_read latency).
@@ -567,6 +599,7 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
                 a_s += 32 * LDK;                                                                               \
                 b_s += CG * LDK;                                                                               \
             }                                                                                                  \
+            EDMP_RCB_RESID(st, t, l, s)                                                                        \
         }                                                                                                      \
     }
 
@@ -587,15 +620,15 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[t], 0, 0, 0);           \
     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[t], 0, 0, 0);           \
     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[t], 0, 0, 0);
-// memory work of one 4-MFMA group q (0..3): items i with i % 4 == q of the A (<= 7) and B (<= 10) staging lists
+// memory work of one 4-MFMA group q (0..3): items i with i % 4 == q of the A (<= 7) and B (<= 12) staging lists
 #define EDMP_RCB_MEM0(LS, SS) EDMP_LD_A##LS(0) EDMP_LD_A##LS(4) EDMP_LD_B##LS(0) EDMP_LD_B##LS(4) EDMP_LD_B##LS(8) \
                               EDMP_ST_A##SS(0) EDMP_ST_A##SS(4) EDMP_ST_B##SS(0) EDMP_ST_B##SS(4) EDMP_ST_B##SS(8)
 #define EDMP_RCB_MEM1(LS, SS) EDMP_LD_A##LS(1) EDMP_LD_A##LS(5) EDMP_LD_B##LS(1) EDMP_LD_B##LS(5) EDMP_LD_B##LS(9) \
                               EDMP_ST_A##SS(1) EDMP_ST_A##SS(5) EDMP_ST_B##SS(1) EDMP_ST_B##SS(5) EDMP_ST_B##SS(9)
-#define EDMP_RCB_MEM2(LS, SS) EDMP_LD_A##LS(2) EDMP_LD_A##LS(6) EDMP_LD_B##LS(2) EDMP_LD_B##LS(6) \
-                              EDMP_ST_A##SS(2) EDMP_ST_A##SS(6) EDMP_ST_B##SS(2) EDMP_ST_B##SS(6)
-#define EDMP_RCB_MEM3(LS, SS) EDMP_LD_A##LS(3) EDMP_LD_B##LS(3) EDMP_LD_B##LS(7) \
-                              EDMP_ST_A##SS(3) EDMP_ST_B##SS(3) EDMP_ST_B##SS(7)
+#define EDMP_RCB_MEM2(LS, SS) EDMP_LD_A##LS(2) EDMP_LD_A##LS(6) EDMP_LD_B##LS(2) EDMP_LD_B##LS(6) EDMP_LD_B##LS(10) \
+                              EDMP_ST_A##SS(2) EDMP_ST_A##SS(6) EDMP_ST_B##SS(2) EDMP_ST_B##SS(6) EDMP_ST_B##SS(10)
+#define EDMP_RCB_MEM3(LS, SS) EDMP_LD_A##LS(3) EDMP_LD_B##LS(3) EDMP_LD_B##LS(7) EDMP_LD_B##LS(11) \
+                              EDMP_ST_A##SS(3) EDMP_ST_B##SS(3) EDMP_ST_B##SS(7) EDMP_ST_B##SS(11)
 #define EDMP_RCB_QMEM(q, LS, SS)                                                                        \
     {                                                                                                   \
         const float* an = (q < KC / 8 - 1) ? a_s + 8 * (q + 1) : a_s + (32 * LDK);                      \
@@ -654,12 +687,14 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
             a_s += 32 * LDK;                                                                                   \
             b_s += CG * LDK;                                                                                   \
             EDMP_RCB_TAPS(0, lp_lo + 1)                                                                        \
+            EDMP_RCB_RESID(st, 0, l, s)                                                                        \
         }                                                                                                      \
         _Pragma("unroll") for (int t = 1; t < NT; ++t) {                                                       \
             const int j = wave + 4 * t;                                                                        \
             if (j < NTILE) {                                                                                   \
                 EDMP_RCB_TILE_SETUP(st, j)                                                                     \
                 EDMP_RCB_TAPS(t, lp_lo)                                                                        \
+                EDMP_RCB_RESID(st, t, l, s)                                                                    \
             }                                                                                                  \
         }                                                                                                      \
     }
@@ -686,6 +721,7 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
 #undef EDMP_RCB_MFMA4
 #undef EDMP_SGB
 #undef EDMP_RCB_COMPUTE
+#undef EDMP_RCB_RESID
 #undef EDMP_RCB_FETCH
 #undef EDMP_RCB_COMMIT
 #undef EDMP_LD_AP
@@ -721,6 +757,22 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
         ad4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.add_res) ad4[i] = *reinterpret_cast<const float4*>(p.add_res + ((size_t)eb * L + l) * p.Cout + ch);
         else if (p.add_tb) ad4[i] = *reinterpret_cast<const float4*>(p.add_tb + ch);
+    }
+    if constexpr (RES) {  // residual conv (+ its bias) straight from the accumulators: 128-byte runs of 32 channels per row
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = wave + 4 * t;
+            if (j < NTILE) {
+                const int l = j / S, s = j % S;
+                const float rb = (t == 0) ? rbias_t0 : rbias_t1;
+                float* ro = p.res_out + (size_t)l * p.Cout + co0 + s * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int b = b0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (b < p.B) ro[(size_t)b * L * p.Cout] = racc[t][r] + rb;
+                }
+            }
+        }
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -1597,16 +1649,17 @@ static int launch_gn(const GnP& p, hipStream_t s) {
     return EDMP_OK;
 }
 
-template <int CG, int L>
+template <int CG, int L, bool RES>
 static int launch_rcb_t(const RcbP& p, hipStream_t s) {
     static bool attr_set = false;
-    constexpr size_t bytes = RcbCfg<CG, L>::lds_bytes();
+    constexpr size_t bytes = RcbCfg<CG, L, RES>::lds_bytes();
+    static_assert(bytes <= 160 * 1024, "fused conv kernel exceeds the 160 KiB LDS of a CU");
     if (!attr_set) {
-        EDMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcb_conv_kernel<CG, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        EDMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcb_conv_kernel<CG, L, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         attr_set = true;
     }
     dim3 grid(p.Cout / CG, (p.B + 31) / 32);
-    hipLaunchKernelGGL((rcb_conv_kernel<CG, L>), grid, dim3(256), bytes, s, p);
+    hipLaunchKernelGGL((rcb_conv_kernel<CG, L, RES>), grid, dim3(256), bytes, s, p);
     return EDMP_OK;
 }
 static bool rcb_supported(int cout, int L, int c1, int c2) {
@@ -1693,10 +1746,11 @@ static int launch_blk(const BlkP& p, int variant, hipStream_t s) {
 }
 static int launch_rcb(const RcbP& p, int L, hipStream_t s) {
     const int cg = p.Cout / 8;
-    if (cg == 64 && L == 2) return launch_rcb_t<64, 2>(p, s);
-    if (cg == 64 && L == 4) return launch_rcb_t<64, 4>(p, s);
-    if (cg == 32 && L == 4) return launch_rcb_t<32, 4>(p, s);
-    if (cg == 32 && L == 7) return launch_rcb_t<32, 7>(p, s);
+    const bool res = p.res_out != nullptr;
+    if (cg == 64 && L == 2) return res ? launch_rcb_t<64, 2, true>(p, s) : launch_rcb_t<64, 2, false>(p, s);
+    if (cg == 64 && L == 4) return res ? launch_rcb_t<64, 4, true>(p, s) : launch_rcb_t<64, 4, false>(p, s);
+    if (cg == 32 && L == 4) return res ? launch_rcb_t<32, 4, true>(p, s) : launch_rcb_t<32, 4, false>(p, s);
+    if (cg == 32 && L == 7) return res ? launch_rcb_t<32, 7, true>(p, s) : launch_rcb_t<32, 7, false>(p, s);
     set_error("no fused conv+GroupNorm kernel for Cout=%d L=%d", p.Cout, L);
     return EDMP_ERR_STATE;
 }
@@ -1817,8 +1871,9 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
         int tb_off;
         double fn, fe;
         int branch;
-        size_t w2, b2, gamma2, beta2, wr, br;  // OP_BLK
+        size_t w2, b2, gamma2, beta2, wr, br;  // OP_BLK; br also = bias of a residual conv folded into an OP_RCB
         int blk;
+        int res_out;  // OP_RCB: buffer receiving the folded residual 1x1 conv (-1: none)
         // fused conv+gn (OP_RCB): uses src1/src2/C1/C2/Lin/Cout/w/b/dst + gamma/beta/res/tb_off
     };
     std::vector<POp> pops;
@@ -1894,6 +1949,7 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
         o.beta = beta;
         o.res = res_buf;
         o.tb_off = tbo;
+        o.res_out = -1;
         o.dst = pool.get();
         o.fn = 2.0 * a.L * cout * (double)cin_true * 5;
         o.fe = 2.0 * (double)valid_pairs(a.L, a.L, 5, 1, 2, false) * cout * (double)(o.C1 + o.C2);
@@ -1901,11 +1957,20 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
         return TH{o.dst, cout, a.L};
     };
     int rcb_idx = 0;
+    bool pack_fail = false;
     auto emit_rcb = [&](TH x, const TH* x2) -> TH {
         const RawRCB& r = inv.rcbs[rcb_idx++];
         const int cin_store = x.C + (x2 ? x2->C : 0);
-        // conv1
+        // conv1 (a residual 1x1 conv folded into the wide fused kernel is packed right behind it, as tap index 5)
+        const bool fold_res = use_fused && r.has_res && getenv("EDMP_NO_RESFOLD") == nullptr && !use_side &&
+                              rcb_supported(r.cout, x.L, x.C, x2 ? x2->C : 0) &&
+                              !((getenv("EDMP_NO_BLOCK") == nullptr) && blk_variant(r.cout, x.L, x.C, x2 ? x2->C : 0, r.has_res));
         size_t w1 = pk.conv(params + r.cb[0].w.off, r.cout, r.cin, 5, cin_store);
+        size_t wr_folded = 0;
+        if (fold_res) {
+            wr_folded = pk.conv(params + r.rw.off, r.cout, r.cin, 1, cin_store);
+            if (wr_folded != w1 + (size_t)5 * r.cout * cin_store) pack_fail = true;  // the kernel addresses it as tap index 5
+        }
         size_t b1 = pk.vec(params + r.cb[0].b.off, r.cout);
         size_t g1 = pk.vec(params + r.cb[0].gw.off, r.cout), be1 = pk.vec(params + r.cb[0].gb.off, r.cout);
         size_t w2 = pk.conv(params + r.cb[1].w.off, r.cout, r.cout, 5, r.cout);
@@ -1952,7 +2017,15 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
             TH h = emit_fused(x, x2, r.cin, r.cout, w1, b1, g1, be1, -1, tb_off);
             int res_buf;
             int rr_buf = -1;
-            if (r.has_res) {
+            if (fold_res) {
+                POp& c1 = pops.back();
+                c1.res_out = pool.get();
+                c1.br = pk.vec(params + r.rb.off, r.cout);
+                c1.fn += 2.0 * x.L * r.cout * (double)r.cin;
+                c1.fe += 2.0 * x.L * r.cout * (double)cin_store;
+                rr_buf = c1.res_out;
+                res_buf = c1.res_out;
+            } else if (r.has_res) {
                 // the residual 1x1 conv only depends on the block input: it runs concurrently with conv1 on the side stream
                 size_t wr = pk.conv(params + r.rw.off, r.cout, r.cin, 1, cin_store);
                 size_t br = pk.vec(params + r.rb.off, r.cout);
@@ -2063,6 +2136,7 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
     u->tb_stride = tb_cursor;
 
     for (auto& o : pops) EDMP_REQUIRE(!((o.kind == OP_GN || o.kind == OP_RCB) && o.res == -2), "identity residual over a channel concat is not supported");
+    EDMP_REQUIRE(!pack_fail, "packer: a folded residual conv does not follow its conv1 taps");
     // allocate
     size_t max_lc = (size_t)N * CP0;
     for (auto& o : pops)
@@ -2149,6 +2223,8 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
             c.C2 = o.C2;
             c.W = u->wpack + o.w;
             c.bias = u->wpack + o.b;
+            c.res_out = o.res_out >= 0 ? u->bufs[o.res_out] : nullptr;
+            c.res_bias = o.res_out >= 0 ? u->wpack + o.br : nullptr;
             c.gamma = u->wpack + o.gamma;
             c.beta = u->wpack + o.beta;
             c.add_tb = nullptr;
