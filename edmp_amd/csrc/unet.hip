@@ -223,6 +223,17 @@ __global__ void pack_input_kernel(const float* __restrict__ x, float* __restrict
     out[i] = (c < C) ? x[((size_t)b * C + c) * N + l] : 0.0f;
 }
 
+#ifdef EDMP_STAMPS  // phase timing experiment (scratch builds only): one wave of one mid-grid workgroup stamps s_memtime
+__device__ unsigned long long g_stamps[8][16];
+#define EDMP_STAMP(k, i)                                                        \
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == gridDim.y / 2) { \
+        g_stamps[k][2 * (i)] = clock64();                                       \
+        g_stamps[k][2 * (i) + 1] = wall_clock64();                              \
+    }
+#else
+#define EDMP_STAMP(k, i)
+#endif
+
 // Implicit-GEMM Conv1d / ConvTranspose1d on the fp32 MFMA.  Block = 256 threads = 4 waves, tile BM samples x BN
 // output channels at ONE output position; K runs over (valid tap, source, channel chunk of KC).
 // LDS tiles are [rows][KC + 4] so that the ds_read_b128 of a 16-lane group hits 16 distinct 4-bank slots.
@@ -241,8 +252,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
     constexpr bool A_FULL = (A_F4 % 256) == 0;
     constexpr bool B_FULL = (B_F4 % 256) == 0;
     constexpr int STAGE = (BM + BN) * LDK;  // floats per pipeline stage: A tile then B tile
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    constexpr int TS = BN + 4;              // row stride of the output tile staged for the float4 store pass
+    constexpr int LDS_FL = (2 * STAGE > BM * TS) ? 2 * STAGE : BM * TS;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FL];
 
+#define EDMP_CSTAMP(i) if constexpr (BM == 64 && BN == 64 && KC == 64) { EDMP_STAMP(6, i) }
+    EDMP_CSTAMP(0)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -342,6 +357,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
         EDMP_LOAD_NEXT();
         EDMP_STORE_STAGE(0);
         __syncthreads();
+        EDMP_CSTAMP(1)
         // steady state: every iteration prefetches chunk kk+1 while the MFMAs consume chunk kk
         for (int kk = 0; kk < nK - 1; ++kk) {
             const int cur = kk & 1;
@@ -386,17 +402,38 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
 #undef EDMP_DECL_A
 #undef EDMP_DECL_B
 
-    // epilogue: + bias, store [b][lo][co].  acc[r]: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+    EDMP_CSTAMP(2)
+    // epilogue: + bias, store [b][lo][co].  acc[r]: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31.
+    // Sixteen dword stores per lane are store-issue-bound (~4.8 k cycles measured); the tile is transposed through LDS
+    // instead and leaves as BM*BN/1024 float4 stores per thread (128-byte runs along the channels).
     const int co = n0 + wn * 32 + (lane & 31);
-    if (co < p.Cout) {
-        const float bias = bias_v;
+    if ((p.Cout & 3) == 0) {
+        __syncthreads();  // every wave is done with the stages
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            lds[(wm * 32 + row) * TS + wn * 32 + (lane & 31)] = acc[r] + bias_v;
+        }
+        __syncthreads();
+        constexpr int NF = (BM * (BN / 4) + 255) / 256;
+#pragma unroll
+        for (int it = 0; it < NF; ++it) {
+            const int f = tid + it * 256;
+            const int row = f / (BN / 4), c4 = (f % (BN / 4)) * 4;
+            const int b = b0 + row;
+            if (f < BM * (BN / 4) && b < p.B && n0 + c4 < p.Cout)
+                *reinterpret_cast<float4*>(p.dst + ((size_t)b * p.Lout + lo) * p.Cout + n0 + c4) = *reinterpret_cast<const float4*>(lds + row * TS + c4);
+        }
+    } else if (co < p.Cout) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             int b = b0 + wm * 32 + row;
-            if (b < p.B) p.dst[((size_t)b * p.Lout + lo) * p.Cout + co] = acc[r] + bias;
+            if (b < p.B) p.dst[((size_t)b * p.Lout + lo) * p.Cout + co] = acc[r] + bias_v;
         }
     }
+    EDMP_CSTAMP(3)
+#undef EDMP_CSTAMP
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -411,16 +448,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
 // That is 32..112 MFMAs per wave per barrier instead of 16, and 8x less activation re-reading than the per-position
 // tiling of conv_mfma_kernel.  grid = (8 groups, B/32): blockIdx.x = group, so one XCD's L2 holds one group's weights.
 
-#ifdef EDMP_STAMPS  // phase timing experiment (scratch builds only): one wave of one mid-grid workgroup stamps s_memtime
-__device__ unsigned long long g_stamps[8][16];
-#define EDMP_STAMP(k, i)                                                        \
-    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == gridDim.y / 2) { \
-        g_stamps[k][2 * (i)] = clock64();                                       \
-        g_stamps[k][2 * (i) + 1] = wall_clock64();                              \
-    }
-#else
-#define EDMP_STAMP(k, i)
-#endif
 
 template <int CG, int L, bool RES = false>
 struct RcbCfg {
@@ -928,7 +955,7 @@ __global__ __launch_bounds__(256) void rcb_rows_kernel(RcbP p) {
     static_assert(NA <= 4 && NB <= 10 && TPW <= 2, "staging macros cover NA <= 4, NB <= 10, two tiles per wave");
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
-    constexpr int SK = (L == 13) ? 0 : (L == 7) ? 1 : 6;
+    constexpr int SK = (L == 13) ? 0 : 1;  // (L = 25, 50 variants share slot 1 with L = 7: the last launch wins)
     EDMP_STAMP(SK, 0)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1366,7 +1393,10 @@ __global__ __launch_bounds__(256) void rcb_block_kernel(BlkP p) {
 #define EDMP_BLK_STATS() group_stats_lds<L>(Y, YS, stat, SB * G, G, CGS, tid);
     EDMP_BLK_STATS()
     __syncthreads();
-    for (int f = tid; f < ROWS * (C / 4); f += 256) {
+#pragma unroll
+    for (int it1 = 0; it1 < (ROWS * (C / 4) + 255) / 256; ++it1) {
+        const int f = tid + it1 * 256;
+        if (f >= ROWS * (C / 4)) break;
         const int r = f / (C / 4), cc = (f % (C / 4)) * 4;
         const int b = r / L, l = r % L;
         const int g = cc >> CGS;
