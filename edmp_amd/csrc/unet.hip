@@ -785,21 +785,33 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
         if (p.add_res) ad4[i] = *reinterpret_cast<const float4*>(p.add_res + ((size_t)eb * L + l) * p.Cout + ch);
         else if (p.add_tb) ad4[i] = *reinterpret_cast<const float4*>(p.add_tb + ch);
     }
-    if constexpr (RES) {  // residual conv (+ its bias) straight from the accumulators: 128-byte runs of 32 channels per row
+    if constexpr (RES) {
+        // residual conv (+ its bias): staged through the Y tile and written as float4 by the same (row, 8-column-part)
+        // mapping as the final pass - sixteen dword stores per lane straight from the accumulators are store-issue-bound
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int j = wave + 4 * t;
             if (j < NTILE) {
                 const int l = j / S, s = j % S;
+                const int cc = s * 32 + (lane & 31);
                 const float rb = (t == 0) ? rbias_t0 : rbias_t1;
-                float* ro = p.res_out + (size_t)l * p.Cout + co0 + s * 32 + (lane & 31);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int b = b0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (b < p.B) ro[(size_t)b * L * p.Cout] = racc[t][r] + rb;
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    Y[row * YS + l * CG + cc] = racc[t][r] + rb;
                 }
             }
         }
+        __syncthreads();
+        if (b0 + erow < p.B) {
+#pragma unroll
+            for (int i = 0; i < NF4; ++i) {
+                const int col = 4 * (epart + 8 * i);
+                const int l = col / CG, ch = co0 + col % CG;
+                *reinterpret_cast<float4*>(p.res_out + ((size_t)(b0 + erow) * L + l) * p.Cout + ch) = *reinterpret_cast<const float4*>(Y + erow * YS + col);
+            }
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
