@@ -1739,7 +1739,7 @@ static int launch_rows(const RcbP& p, int variant, hipStream_t s) {
         case 2: return launch_rows_t<32, 50, 2, 32>(p, s);
         case 3: return launch_rows_t<32, 25, 5, 32>(p, s);
         case 4: return launch_rows_t<64, 25, 5, 32>(p, s);
-        case 5: return launch_rows_t<64, 13, 4, 32>(p, s);
+        case 5: return launch_rows_t<64, 13, 8, 32>(p, s);  // 8 samples: 256 workgroups = ONE round on 256 CUs (4 samples ran two rounds, each with its own prologue + epilogue)
         case 6: return launch_rows_t<64, 7, 9, 32>(p, s);
     }
     set_error("no narrow fused kernel variant %d", variant);
