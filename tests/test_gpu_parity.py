@@ -133,9 +133,12 @@ def test_fused_and_unfused_paths_agree(monkeypatch):
     sd = W.init_state_dict(12, 7, 32, FULL_DIMS)
     x = torch.tensor(np.random.RandomState(4).standard_normal((33, 7, 50)), dtype=torch.float32)
     a = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, state_dict=sd, max_batch=33)(x, torch.tensor([9.0])).cpu().numpy()
-    monkeypatch.setenv("EDMP_NO_FUSED", "1")
-    b = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, state_dict=sd, max_batch=33)(x, torch.tensor([9.0])).cpu().numpy()
-    assert rmse(a, b) <= 1e-5, rmse(a, b)
+    # every program-builder switch gives the same network: no residual fold, no whole-block kernels, no fusion at all
+    for env in ("EDMP_NO_RESFOLD", "EDMP_NO_BLOCK", "EDMP_NO_FUSED"):
+        monkeypatch.setenv(env, "1")
+        b = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, state_dict=sd, max_batch=33)(x, torch.tensor([9.0])).cpu().numpy()
+        monkeypatch.delenv(env)
+        assert rmse(a, b) <= 1e-5, (env, rmse(a, b))
 
 
 def test_obstacle_table(golden):
