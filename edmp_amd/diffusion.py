@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _capi, franka
+from . import _capi, franka, nprng
 from .runtime import get_context, ptr
 
 
@@ -15,8 +15,9 @@ def draw_noise(T: int, batch_size: int, num_channels: int, traj_len: int) -> np.
     """(T+1, B, C, N) f64 from the GLOBAL NumPy RandomState in the reference's call order: one
     ``multivariate_normal(0, I_N, size=(B, C))`` for X_T (diffusion.py:303) then one per step (diffusion.py:126).
     With an identity covariance that call consumes the stream exactly like ``standard_normal((B, C, N))``
-    (pinned by tests/test_host.py), so all draws are made in one vectorised call."""
-    return np.random.standard_normal((T + 1, batch_size, num_channels, traj_len))
+    (pinned by tests/test_host.py), so all draws are made in one vectorised call - by edmp_amd.nprng, which produces
+    NumPy's legacy stream bit for bit on all host cores and advances the global state exactly like NumPy."""
+    return nprng.standard_normal((T + 1, batch_size, num_channels, traj_len))
 
 
 class Diffusion:
@@ -43,7 +44,7 @@ class Diffusion:
         ctx.ensure_sampler(self.T, self.variance_thresh)
         b, c, n = xt.shape
         if z is None:
-            z = np.random.standard_normal((b, c, n))
+            z = nprng.standard_normal((b, c, n))
         X = ctx.to_dev(np.array(xt, dtype=np.float64), torch.float64)  # a fresh device tensor: updated in place below
         e = ctx.to_dev(eps, torch.float32)
         zd = ctx.to_dev(np.asarray(z, dtype=np.float64), torch.float64)
@@ -58,7 +59,7 @@ class Diffusion:
         b, c, n = x.shape
         t = np.ascontiguousarray(np.broadcast_to(np.asarray(t), (b,)), dtype=np.int32)
         if eps is None:  # diffusion.py:68-71 / 95-98: an identity-covariance multivariate normal == standard normal draws
-            eps = np.random.standard_normal((b, c * n)).reshape(b, c, n)
+            eps = nprng.standard_normal((b, c * n)).reshape(b, c, n)
         xd = ctx.to_dev(x, torch.float64)
         ed = ctx.to_dev(np.ascontiguousarray(eps, dtype=np.float64), torch.float64)
         xt = ctx.empty((b, c, n), torch.float64)
@@ -83,7 +84,7 @@ class Diffusion:
         b, c, n = x0.shape
         if time_steps is None:
             time_steps = np.random.randint(1, self.T + 1, size=(b,))
-        eps = np.random.standard_normal((b, c, n))  # == multivariate_normal(0, I_n, size=(b, c))   (diffusion.py:231)
+        eps = nprng.standard_normal((b, c, n))  # == multivariate_normal(0, I_n, size=(b, c))   (diffusion.py:231)
         xt, means, t = self._q(x0, time_steps, eps, cumulative=1, condition=condition)
         vars_ = np.sqrt(1 - self.alpha_bar[t - 1, np.newaxis, np.newaxis])
         if return_type == "tensor":
@@ -161,13 +162,13 @@ class Diffusion:
         if noise is None:
             # Reference contract: z comes from the GLOBAL NumPy RandomState, X_T first, then one draw per step
             # (diffusion.py:303, 126).  The stream is drawn in chunks of `chunk_steps` steps and each chunk is uploaded and
-            # enqueued at once, so the host RNG (the slower side: ~3.3 ms per step for 1024 rows) runs while the GPU
+            # enqueued at once, so the host RNG (edmp_amd.nprng: ~0.9 ms per step for 1024 rows on 16 cores; NumPy itself needs 3.3-4 ms) runs while the GPU
             # denoises the previous chunk.  The numbers and their order are those of one big standard_normal call.
             guided = 1 if guide is not None else 0
             t_hi, first, keep = self.T, True, []
             while t_hi > t_stop:
-                k = min(int(chunk_steps), t_hi - t_stop)
-                z = np.random.standard_normal((k + (1 if first else 0), batch_size, num_channels, traj_len))
+                k = min(int(chunk_steps) if not first else max(1, int(chunk_steps) // 4), t_hi - t_stop)  # short first chunk: the GPU starts sooner
+                z = nprng.standard_normal((k + (1 if first else 0), batch_size, num_channels, traj_len))
                 zd = ctx.to_dev(z, torch.float64)
                 keep.append(zd)  # stays allocated until the stream has consumed it
                 last = (t_hi - k) == t_stop

@@ -75,6 +75,37 @@ def test_noise_stream_equals_reference_draw_order():
         assert np.array_equal(mine[i], ref[i])
 
 
+def test_parallel_legacy_normal_stream_is_numpys_bit_for_bit():
+    """edmp_amd.nprng (libedmp_nprng.so): the values AND the global RandomState afterwards are NumPy's own, for even / odd
+    counts, with and without a cached second gaussian going in, across the multi-block threshold, with any thread count."""
+    from edmp_amd import nprng
+
+    if not nprng.available():
+        pytest.skip("libedmp_nprng.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    block = 2 * (1 << 18)  # values one bulk block can yield at most
+    for seed, warm, n in [(1, 0, 4096), (2, 3, 4097), (3, 4, 100_001), (4, 1, 2 * block + 12_345), (5, 0, 3 * block)]:
+        np.random.seed(seed)
+        np.random.standard_normal(warm)  # an odd warm-up leaves a cached gaussian in the state
+        want = np.random.standard_normal(n)
+        after = (np.random.standard_normal(5), np.random.random_sample(3), np.random.randint(0, 1 << 30, 4))
+        for nthreads in (1, 3, None):
+            np.random.seed(seed)
+            np.random.standard_normal(warm)
+            got = nprng.standard_normal(n, nthreads=nthreads)
+            assert got.dtype == np.float64 and np.array_equal(got, want), (seed, n, nthreads)
+            for a, b in zip(after, (np.random.standard_normal(5), np.random.random_sample(3), np.random.randint(0, 1 << 30, 4))):
+                assert np.array_equal(a, b), (seed, n, nthreads, "state after the call")
+    # shapes, and the small-size / foreign-bit-generator fallbacks stay NumPy's
+    np.random.seed(7)
+    a = np.random.standard_normal((3, 5, 7, 50))
+    np.random.seed(7)
+    assert np.array_equal(nprng.standard_normal((3, 5, 7, 50)), a)
+    np.random.seed(8)
+    b = np.random.standard_normal((40, 7, 50))
+    np.random.seed(8)
+    assert np.array_equal(nprng.standard_normal((40, 7, 50)), b)
+
+
 def test_weights_inventory():
     from edmp_amd import weights as W
 
