@@ -465,9 +465,58 @@ struct RcbCfg {
     static constexpr int NB = NSLAB * CG / 32;
     static constexpr int YS = L * CG + 4;
     static constexpr int NF4 = L * CG / 32;  // float4 per thread in the epilogue
+    // Split-K mode: instead of owning output tiles, a wave owns a SLICE of each 32-channel K chunk (8 channels with one
+    // 32-channel output slab per group, 16 with two) and accumulates ALL L tiles of its slab over it.  All waves then
+    // run the same, fully static instruction stream (no per-wave tile/position loops, no imbalance between edge and
+    // centre positions), the A fragment of an input position is loaded once and reused by every tile it feeds, and
+    // consecutive MFMA groups go to different accumulators.  The partial tiles are summed when the epilogue reads them
+    // back from LDS.
+#ifdef EDMP_NO_SPLITK
+    static constexpr bool SK = false;
+#else
+    // used where a group is one 32-channel slab: there the per-position tile ownership leaves edge-position waves idle
+    // (3 vs 4 or 5 taps).  Measured: <32,7> 44.8 -> 40.4 us, <32,4> 23.8 -> 22.1 us, <32,4,RES> 97.7 -> 91 us.  With two
+    // slabs the tile ownership is already balanced: split-K measured slower at L = 2 (24.2 -> 25.8 us) and spills at L = 4;
+    // the L = 7 residual variant (14 accumulators) spills too.
+    static constexpr bool SK = (S == 1) && !(RES && L > 4);
+#endif
+    // a wave = (output slab s = wave % S, K slice ks = wave / S): KSPLIT waves share a slab, each taking QW of the
+    // chunk's four 8-channel K groups
+    static constexpr int KSPLIT = SK ? 4 / S : 1;
+    static constexpr int QW = 4 / (4 / S);
+    static constexpr int NP = SK ? KSPLIT : 1;   // partial output tiles in LDS
+    static constexpr int NACC = SK ? L : NT;     // accumulators per wave
+    // the MFMA groups (4 MFMAs each) of one split-K step: for every input position lp and every K group q of the wave,
+    // the tiles l with |l - lp| <= 2 (weight slab lp - l + 2 - KT0), then the residual conv of tile lp (slab NTAP) -
+    // so the A fragment (lp, q) is loaded once and feeds up to six groups
+    static constexpr int sk_groups() {
+        int n = 0;
+        for (int lp = 0; lp < L; ++lp)
+            for (int q = 0; q < QW; ++q) {
+                for (int l = (lp - 2 > 0 ? lp - 2 : 0); l <= (lp + 2 < L - 1 ? lp + 2 : L - 1); ++l) ++n;
+                if (RES) ++n;
+            }
+        return n;
+    }
+    // what = 0: input position, 1: output tile, 2: weight slab, 3: is-residual, 4: K group q
+    static constexpr int sk_group(int g, int what) {
+        int n = 0;
+        for (int lp = 0; lp < L; ++lp)
+            for (int q = 0; q < QW; ++q) {
+                for (int l = (lp - 2 > 0 ? lp - 2 : 0); l <= (lp + 2 < L - 1 ? lp + 2 : L - 1); ++l) {
+                    if (n == g) return what == 0 ? lp : what == 1 ? l : what == 2 ? lp - l + 2 - KT0 : what == 3 ? 0 : q;
+                    ++n;
+                }
+                if (RES) {
+                    if (n == g) return what == 0 ? lp : what == 1 ? lp : what == 2 ? NTAP : what == 3 ? 1 : q;
+                    ++n;
+                }
+            }
+        return 0;
+    }
     static constexpr size_t lds_bytes() {
         size_t b = 2 * (size_t)STAGE * sizeof(float);
-        size_t y = 32 * (size_t)YS * sizeof(float);
+        size_t y = (size_t)NP * 32 * (size_t)YS * sizeof(float);
         size_t m = b > y ? b : y;
 #ifdef EDMP_EXP_NOPIN
         return m;
@@ -481,6 +530,8 @@ template <int CG, int L, bool RES>
 __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
     using Cf = RcbCfg<CG, L, RES>;
     constexpr int KC = Cf::KC, LDK = Cf::LDK, S = Cf::S, NTILE = Cf::NTILE, NT = Cf::NT, KT0 = Cf::KT0, NTAP = Cf::NTAP;
+    constexpr bool SPK = Cf::SK;  // split-K mode
+    constexpr int NP = Cf::NP, NACC = Cf::NACC;
     constexpr int A_FL = Cf::A_FL, STAGE = Cf::STAGE, NA = Cf::NA, NB = Cf::NB, YS = Cf::YS, NF4 = Cf::NF4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -549,9 +600,9 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
         float* sn_ = (stage_ptr);                              \
         EDMP_REP7(EDMP_ST_A##SET) EDMP_REP10(EDMP_ST_B##SET)   \
     }
-    f32x16 acc[NT];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
     // the conv bias of this wave's tiles is requested NOW: loaded where it is used (first thing of the epilogue) it would
@@ -560,11 +611,11 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
     const float bias_t0 = p.bias[co0 + (wave % S) * 32 + (lane & 31)];
     const float bias_t1 = p.bias[co0 + (min(wave + 4, NTILE - 1) % S) * 32 + (lane & 31)];
     // folded residual 1x1 conv (RES): a second accumulator per tile, fed by the centre input position against weight slab NTAP
-    f32x16 racc[RES ? NT : 1];
+    f32x16 racc[RES ? NACC : 1];
     float rbias_t0 = 0.f, rbias_t1 = 0.f;
     if constexpr (RES) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NACC; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) racc[t][i] = 0.0f;
         rbias_t0 = p.res_bias[co0 + (wave % S) * 32 + (lane & 31)];
@@ -726,17 +777,92 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
         }                                                                                                      \
     }
     static_assert(KC == 32 && NTILE >= 4 && L >= 2, "EDMP_RCB_STEP: 4 MFMA groups per position, a tile 0 with >= 2 positions per wave");
-    int kk = 0;
-    for (; kk + 1 < nK; kk += 2) {
-        EDMP_RCB_STEP(lds, P, kk + 2, Q, lds + STAGE)
-        __syncthreads();
-        EDMP_RCB_STEP(lds + STAGE, Q, kk + 3, P, lds)
-        __syncthreads();
+// ---- split-K step (Cf::SK): this wave's K slice = channels [8*wave, 8*wave+8) of the chunk; the groups of Cf::sk_group
+// in order, fragments of group g+1 requested before the MFMAs of group g, the step's staging traffic on the first four
+#define EDMP_SK_MEMSEL(g, LS, SS)                      \
+    if ((g) == 0) { EDMP_RCB_MEM0(LS, SS) }            \
+    else if ((g) == 1) { EDMP_RCB_MEM1(LS, SS) }       \
+    else if ((g) == 2) { EDMP_RCB_MEM2(LS, SS) }       \
+    else if ((g) == 3) { EDMP_RCB_MEM3(LS, SS) }
+#define EDMP_SK_STEP(st, LS, nc, SS, stn)                                                                      \
+    {                                                                                                          \
+        const int nc_ = min((nc), nK - 1);                                                                     \
+        const bool first_ = nc_ < ch1;                                                                         \
+        const float* src_ = first_ ? p.src1 : p.src2;                                                          \
+        const int Cs_ = first_ ? p.C1 : p.C2;                                                                  \
+        const int ci0_ = (first_ ? nc_ : nc_ - ch1) * KC;                                                      \
+        const int ag_ = (first_ ? a_g1 : a_g2) + ci0_;                                                         \
+        const int wofs_ = (first_ ? 0 : p.C1) + ci0_;                                                          \
+        float* sn_ = (stn);                                                                                    \
+        const float* sa_ = (st) + frag + 8 * Cf::QW * (wave / S);                                              \
+        const float* sb_ = (st) + A_FL + ((wave % S) * 32) * LDK + frag + 8 * Cf::QW * (wave / S);             \
+        float4 a4 = *reinterpret_cast<const float4*>(sa_ + Cf::sk_group(0, 0) * (32 * LDK) + 8 * Cf::sk_group(0, 4)); \
+        float4 b4 = *reinterpret_cast<const float4*>(sb_ + Cf::sk_group(0, 2) * (CG * LDK) + 8 * Cf::sk_group(0, 4)); \
+        _Pragma("unroll") for (int g = 0; g < NGRP; ++g) {                                                     \
+            const int tl_ = Cf::sk_group(g, 1);                                                                \
+            const bool isres_ = Cf::sk_group(g, 3) != 0;                                                       \
+            float4 a4n = a4, b4n = b4;                                                                         \
+            if (g + 1 < NGRP) {                                                                                \
+                if (Cf::sk_group(g + 1, 0) != Cf::sk_group(g, 0) || Cf::sk_group(g + 1, 4) != Cf::sk_group(g, 4)) \
+                    a4n = *reinterpret_cast<const float4*>(sa_ + Cf::sk_group(g + 1, 0) * (32 * LDK) + 8 * Cf::sk_group(g + 1, 4)); \
+                b4n = *reinterpret_cast<const float4*>(sb_ + Cf::sk_group(g + 1, 2) * (CG * LDK) + 8 * Cf::sk_group(g + 1, 4));     \
+            }                                                                                                  \
+            EDMP_SK_MEMSEL(g, LS, SS)                                                                          \
+            if (isres_) {                                                                                      \
+                if constexpr (RES) {                                                                           \
+                    racc[tl_] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, racc[tl_], 0, 0, 0);          \
+                    racc[tl_] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, racc[tl_], 0, 0, 0);          \
+                    racc[tl_] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, racc[tl_], 0, 0, 0);          \
+                    racc[tl_] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, racc[tl_], 0, 0, 0);          \
+                }                                                                                              \
+            } else {                                                                                           \
+                acc[tl_] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[tl_], 0, 0, 0);                \
+                acc[tl_] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[tl_], 0, 0, 0);                \
+                acc[tl_] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[tl_], 0, 0, 0);                \
+                acc[tl_] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[tl_], 0, 0, 0);                \
+            }                                                                                                  \
+            a4 = a4n;                                                                                          \
+            b4 = b4n;                                                                                          \
+            if (g < 4) {                                                                                       \
+                EDMP_SGB(0x100, 2)                                                                             \
+                EDMP_SGB(0x008, 1) EDMP_SGB(0x020, 2) EDMP_SGB(0x200, 2)                                       \
+                EDMP_SGB(0x008, 1) EDMP_SGB(0x020, 1) EDMP_SGB(0x200, 1)                                       \
+                EDMP_SGB(0x008, 1) EDMP_SGB(0x020, 1) EDMP_SGB(0x200, 1)                                       \
+                EDMP_SGB(0x008, 1) EDMP_SGB(0x020, 1) EDMP_SGB(0x200, 1)                                       \
+            } else {                                                                                           \
+                EDMP_SGB(0x100, 2) EDMP_SGB(0x008, 4)                                                          \
+            }                                                                                                  \
+        }                                                                                                      \
     }
-    if (kk < nK) {  // odd chunk count: the last chunk sits in stage 0
-        EDMP_RCB_COMPUTE(lds)
-        __syncthreads();
+    if constexpr (SPK) {
+        constexpr int NGRP = Cf::sk_groups();
+        static_assert(NGRP >= 4, "the first four groups carry the staging traffic");
+        int kk = 0;
+        for (; kk + 1 < nK; kk += 2) {
+            EDMP_SK_STEP(lds, P, kk + 2, Q, lds + STAGE)
+            __syncthreads();
+            EDMP_SK_STEP(lds + STAGE, Q, kk + 3, P, lds)
+            __syncthreads();
+        }
+        if (kk < nK) {  // odd chunk count: the last chunk sits in stage 0 (its fetch / commit are harmless repeats)
+            EDMP_SK_STEP(lds, P, kk + 2, Q, lds + STAGE)
+            __syncthreads();
+        }
+    } else {
+        int kk = 0;
+        for (; kk + 1 < nK; kk += 2) {
+            EDMP_RCB_STEP(lds, P, kk + 2, Q, lds + STAGE)
+            __syncthreads();
+            EDMP_RCB_STEP(lds + STAGE, Q, kk + 3, P, lds)
+            __syncthreads();
+        }
+        if (kk < nK) {  // odd chunk count: the last chunk sits in stage 0
+            EDMP_RCB_COMPUTE(lds)
+            __syncthreads();
+        }
     }
+#undef EDMP_SK_STEP
+#undef EDMP_SK_MEMSEL
 #undef EDMP_RCB_STEP
 #undef EDMP_RCB_TILE_SETUP
 #undef EDMP_RCB_TAPS
@@ -788,17 +914,29 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
     if constexpr (RES) {
         // residual conv (+ its bias): staged through the Y tile and written as float4 by the same (row, 8-column-part)
         // mapping as the final pass - sixteen dword stores per lane straight from the accumulators are store-issue-bound
+        if constexpr (SPK) {  // every wave holds a K-slice partial of every tile of its slab: partial buffer wave / S, bias in partial 0
+            float* Yw = Y + (wave / S) * (32 * YS);
+            const float rb = (wave / S == 0) ? rbias_t0 : 0.0f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int j = wave + 4 * t;
-            if (j < NTILE) {
-                const int l = j / S, s = j % S;
-                const int cc = s * 32 + (lane & 31);
-                const float rb = (t == 0) ? rbias_t0 : rbias_t1;
+            for (int l = 0; l < L; ++l)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    Y[row * YS + l * CG + cc] = racc[t][r] + rb;
+                    Yw[row * YS + l * CG + (wave % S) * 32 + (lane & 31)] = racc[l][r] + rb;
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int j = wave + 4 * t;
+                if (j < NTILE) {
+                    const int l = j / S, s = j % S;
+                    const int cc = s * 32 + (lane & 31);
+                    const float rb = (t == 0) ? rbias_t0 : rbias_t1;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        Y[row * YS + l * CG + cc] = racc[t][r] + rb;
+                    }
                 }
             }
         }
@@ -808,22 +946,40 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
             for (int i = 0; i < NF4; ++i) {
                 const int col = 4 * (epart + 8 * i);
                 const int l = col / CG, ch = co0 + col % CG;
-                *reinterpret_cast<float4*>(p.res_out + ((size_t)(b0 + erow) * L + l) * p.Cout + ch) = *reinterpret_cast<const float4*>(Y + erow * YS + col);
+                float4 rv = *reinterpret_cast<const float4*>(Y + erow * YS + col);
+#pragma unroll
+                for (int q = 1; q < NP; ++q) {
+                    const float4 pv = *reinterpret_cast<const float4*>(Y + q * (32 * YS) + erow * YS + col);
+                    rv.x += pv.x, rv.y += pv.y, rv.z += pv.z, rv.w += pv.w;
+                }
+                *reinterpret_cast<float4*>(p.res_out + ((size_t)(b0 + erow) * L + l) * p.Cout + ch) = rv;
             }
         }
         __syncthreads();
     }
+    if constexpr (SPK) {
+        float* Yw = Y + (wave / S) * (32 * YS);
+        const float bias = (wave / S == 0) ? bias_t0 : 0.0f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int j = wave + 4 * t;
-        if (j < NTILE) {
-            const int l = j / S, s = j % S;
-            const int cc = s * 32 + (lane & 31);
-            const float bias = (t == 0) ? bias_t0 : bias_t1;
+        for (int l = 0; l < L; ++l)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                Y[row * YS + l * CG + cc] = acc[t][r] + bias;
+                Yw[row * YS + l * CG + (wave % S) * 32 + (lane & 31)] = acc[l][r] + bias;
+            }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = wave + 4 * t;
+            if (j < NTILE) {
+                const int l = j / S, s = j % S;
+                const int cc = s * 32 + (lane & 31);
+                const float bias = (t == 0) ? bias_t0 : bias_t1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    Y[row * YS + l * CG + cc] = acc[t][r] + bias;
+                }
             }
         }
     }
@@ -837,6 +993,11 @@ __global__ __launch_bounds__(256) void rcb_conv_kernel(RcbP p) {
 #pragma unroll
         for (int i = 0; i < NF4; ++i) {
             v[i] = *reinterpret_cast<const float4*>(Y + row * YS + 4 * (part + 8 * i));
+#pragma unroll
+            for (int q = 1; q < NP; ++q) {  // split-K: the tile is the sum of the four waves' partial tiles
+                const float4 pv = *reinterpret_cast<const float4*>(Y + q * (32 * YS) + row * YS + 4 * (part + 8 * i));
+                v[i].x += pv.x, v[i].y += pv.y, v[i].z += pv.z, v[i].w += pv.w;
+            }
             sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
         sum += __shfl_xor(sum, 1, 64);
