@@ -165,20 +165,33 @@ class Diffusion:
             # enqueued at once, so the host RNG (edmp_amd.nprng: ~0.9 ms per step for 1024 rows on 16 cores; NumPy itself needs 3.3-4 ms) runs while the GPU
             # denoises the previous chunk.  The numbers and their order are those of one big standard_normal call.
             guided = 1 if guide is not None else 0
-            t_hi, first, keep = self.T, True, []
-            while t_hi > t_stop:
-                k = min(int(chunk_steps) if not first else max(1, int(chunk_steps) // 4), t_hi - t_stop)  # short first chunk: the GPU starts sooner
-                z = nprng.standard_normal((k + (1 if first else 0), batch_size, num_channels, traj_len))
-                zd = ctx.to_dev(z, torch.float64)
-                keep.append(zd)  # stays allocated until the stream has consumed it
-                last = (t_hi - k) == t_stop
-                _capi.check(
-                    ctx.lib.edmp_denoise_guided_segment_dev(ctx.h, ptr(zd), batch_size, _capi.as_pd(s), _capi.as_pd(g), guided, t_hi, t_hi - k,
-                                                            1 if first else 0, 1 if zero_row0 else 0, ptr(out) if last else None),
-                    "edmp_denoise_guided_segment_dev",
-                )
-                t_hi -= k
+            # chunk plan: (steps, carries X_T); the first chunk is short so that the GPU starts sooner
+            plan, t_left, first = [], self.T - int(t_stop), True
+            while t_left > 0:
+                k = min(int(chunk_steps) if not first else max(1, int(chunk_steps) // 4), t_left)
+                plan.append((k, first))
+                t_left -= k
                 first = False
+            shape = lambda k, f: (k + (1 if f else 0), batch_size, num_channels, traj_len)  # noqa: E731
+            # the draws run in ONE background thread (the C helper releases the GIL), strictly in order, so chunk i+1 is
+            # being drawn while this thread uploads chunk i and enqueues its ~1000 kernel launches
+            from concurrent.futures import ThreadPoolExecutor
+
+            t_hi, keep = self.T, []
+            with ThreadPoolExecutor(max_workers=1) as pool:
+                pending = pool.submit(nprng.standard_normal, shape(*plan[0])) if plan else None
+                for i, (k, f) in enumerate(plan):
+                    z = pending.result()
+                    pending = pool.submit(nprng.standard_normal, shape(*plan[i + 1])) if i + 1 < len(plan) else None
+                    zd = ctx.to_dev_overlapped(z, torch.float64)  # copy stream: the upload runs beside the previous chunk's kernels
+                    keep.append(zd)  # stays allocated until the stream has consumed it
+                    last = i + 1 == len(plan)
+                    _capi.check(
+                        ctx.lib.edmp_denoise_guided_segment_dev(ctx.h, ptr(zd), batch_size, _capi.as_pd(s), _capi.as_pd(g), guided, t_hi, t_hi - k,
+                                                                1 if f else 0, 1 if zero_row0 else 0, ptr(out) if last else None),
+                        "edmp_denoise_guided_segment_dev",
+                    )
+                    t_hi -= k
             if return_device:
                 ctx.sync()
                 return out

@@ -53,6 +53,19 @@ class Context:
                 t = torch.from_numpy(np.ascontiguousarray(arr)).to(dtype=dtype).to(self.device)
         return t
 
+    def to_dev_overlapped(self, arr: np.ndarray, dtype) -> torch.Tensor:
+        """host ndarray -> device tensor through a SEPARATE copy stream (the DMA engine then runs beside the kernels of
+        this context's stream instead of in line with them); this context's stream is ordered after the copy.  The caller
+        keeps the tensor alive until the work that reads it has been enqueued AND completed (or synchronises)."""
+        if not hasattr(self, "copy_stream"):
+            with torch.cuda.device(self.device):
+                self.copy_stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self.copy_stream):
+            t = torch.from_numpy(np.ascontiguousarray(arr)).to(dtype=dtype).to(self.device)
+        t.record_stream(self.stream)
+        self.stream.wait_stream(self.copy_stream)
+        return t
+
     def empty(self, shape, dtype) -> torch.Tensor:
         with torch.cuda.stream(self.stream):
             return torch.empty(shape, dtype=dtype, device=self.device)
