@@ -51,6 +51,11 @@ def pmc_traffic():
         return None
 
 
+def traffic_bytes_per_launch(detail):
+    """`roofline.traffic` proper: HBM bytes per launch of the dominant kernel family (a number, or None)."""
+    return None if not detail else float(detail["hbm_MB_per_launch"]) * 1e6
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,7 +197,8 @@ def main():
             "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s",
             "frac": ach / PEAK_F32_MFMA_TFLOPS,
-            "traffic": pmc_traffic(),
+            "traffic": traffic_bytes_per_launch(pmc_traffic()),  # HBM bytes per conv launch (PMC FETCH_SIZE x2 + WRITE_SIZE passes)
+            "traffic_detail": pmc_traffic(),
             "achieved_executed": conv_exec * B * T / (conv_ms * 1e-3) / 1e12,
             "launches": launches,
             "avg_launch_us": 1e3 * conv_ms / max(launches, 1),
