@@ -5,17 +5,19 @@
 // :202-260 Down/Middle/Up samplers).  Design:
 //   * activations live in HBM as [B][L][C] fp32 (channels innermost) so that every conv tap of one output position
 //     is a contiguous C-vector per sample; conv weights are repacked once to [tap][Cout][Cin].
-//   * all matrix work is v_mfma_f32_32x32x2_f32 (exact fp32).  Three kernel families:
-//       rcb_conv_kernel  wide levels (Cout 256/512, L 2/4/7): Conv1d k5 + bias + GroupNorm + Mish + add, one launch;
-//                        workgroup = 32 samples x one GroupNorm group x all L positions.
+//   * all matrix work is v_mfma_f32_32x32x2_f32 (exact fp32).  Four kernel families:
+//       rcb_conv_kernel  wide levels (Cout 256/512, L 2/4/7): Conv1d k5 + bias + GroupNorm + Mish + add, one launch
+//                        (+ the block's residual 1x1 conv folded in); workgroup = 32 samples x one GroupNorm group x
+//                        all L positions; split-K wave ownership where a group is one 32-channel slab.
 //       rcb_rows_kernel  narrow levels (Cout <= 128, L 7..50): the same fusion with GEMM rows = (sample, position);
 //                        workgroup = a few whole samples x 32/64 channels, taps read from one zero-haloed LDS tile.
-//       conv_mfma_kernel everything else (k3 s2, ConvTranspose k4 s2, 1x1 residual convs): implicit GEMM per output
-//                        position; also the whole net with gn_mish_kernel when EDMP_NO_FUSED=1.
+//       rcb_block_kernel the 32/64-channel levels: a whole ResidualConvolutionBlock per launch (hidden activation in LDS).
+//       conv_mfma_kernel everything else (k3 s2, ConvTranspose k4 s2, the two remaining 1x1 residual convs): implicit
+//                        GEMM per output position; also the whole net with gn_mish_kernel when EDMP_NO_FUSED=1.
 //     Taps that fall into the zero padding are never issued (at L=2 only 2 of 5 taps exist): 122.0 of the 187.3
 //     nominal MFLOP per trajectory-step are executed.
 //   * the whole time-embedding MLP chain depends on t only and is precomputed for t = 1..T at load (time_table_kernel).
-//   * the layer program (which kernel, which buffers) is built once in edmp_unet_load; a forward is ~70 launches.
+//   * the layer program (which kernel, which buffers) is built once in edmp_unet_load; a forward is 53 conv launches (+ input pack and head).
 #include "common.h"
 
 namespace edmp {
