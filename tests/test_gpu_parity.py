@@ -225,6 +225,48 @@ def test_gradient_vs_oracle_random(oracle):
         assert maxabs(a, b) <= 5e-5 and rmse(a, b) <= 3e-6, (t, maxabs(a, b), rmse(a, b))
 
 
+@pytest.mark.parametrize("n_obstacles,bpg,guides", [(1, 1, [1]), (1, 2, [10, 13]), (64, 1, [1, 2, 3, 4, 5, 10]), (7, 1, [11, 18, 9])])
+def test_guide_edge_sizes_vs_oracle(oracle, n_obstacles, bpg, guides):
+    """one obstacle, the maximum number of obstacles (EDMP_MAX_OBSTACLES = 64), single-row batches, ragged trajectory
+    lengths: costs, swept-volume costs, gradient and the best-row choice against the oracle."""
+    from edmp_amd import scenes
+    from edmp_amd.guide import IntersectionVolumeGuide
+
+    cfgs = cfgs_for(guides, bpg)
+    B = cfgs["total_batch_size"]
+    scene = scenes.random_scene(40 + n_obstacles, n_obstacles)
+    guide = IntersectionVolumeGuide(scene, DEV, cfgs, B)
+    og = oracle.GuideOracle(scene, cfgs, B)
+    rs = np.random.RandomState(n_obstacles)
+    lo, hi = oracle.joint_limits()
+    s, gl = scenes.random_start_goal(3)
+    for L in (48, 1, 5):
+        q = oracle.clip_joints(rs.uniform(lo[None, :, None], hi[None, :, None], (B, 7, L)))
+        for t in (0, 200, 6):
+            if t == 0:
+                qa = q[:1] if B > 1 else q  # t = 0 evaluates any number of rows against the un-inflated scene
+                a = guide.cost(torch.tensor(qa), 0, batch_size=qa.shape[0]).cpu().numpy()
+                b = og.cost(torch.tensor(qa, dtype=torch.float32), 0, batch_size=qa.shape[0]).numpy()
+            else:
+                a = guide.cost(torch.tensor(q), t).cpu().numpy()
+                b = og.cost(torch.tensor(q, dtype=torch.float32), t).numpy()
+            assert a.shape == b.shape and maxabs(a, b) <= 2e-6, (L, t, maxabs(a, b))
+        if L >= 2:
+            for t in (254, 6):
+                a = guide.get_gradient(q, s, gl, t)
+                b = og.get_gradient(q, s, gl, t)
+                # a batch whose gradient is exactly zero (one small obstacle, nothing touches it) turns into NaN
+                # everywhere in the reference (quirk Q7: g / ||g||): the NaN pattern must match too
+                assert np.array_equal(np.isnan(a), np.isnan(b)), (L, t)
+                fin = ~np.isnan(b)
+                if fin.any():
+                    assert maxabs(a[fin], b[fin]) <= 5e-5 and rmse(a[fin], b[fin]) <= 5e-6, (L, t, maxabs(a[fin], b[fin]))
+    traj = oracle.clip_joints(rs.uniform(lo[None, :, None], hi[None, :, None], (B, 7, 50)))
+    va, ia = guide.row_swept_volumes(s, gl, traj)
+    vb = og.row_swept_volumes(s, gl, traj)
+    assert maxabs(va, np.asarray(vb)) <= 2e-5 and ia == int(np.argmin(np.asarray(vb)))
+
+
 @pytest.mark.parametrize("tag", ["c1_g1_b4", "c3_g6_b12", "mixed_b12"])
 def test_teacher_forced_steps(golden, tiny_net, tag):
     """Every kept step of the reference's own run: feed its X_t and z_t, compare eps, posterior, gradient, X_{t-1}."""
