@@ -199,6 +199,9 @@ def main():
             "frac": ach / PEAK_F32_MFMA_TFLOPS,
             "traffic": traffic_bytes_per_launch(pmc_traffic()),  # HBM bytes per conv launch (PMC FETCH_SIZE x2 + WRITE_SIZE passes)
             "traffic_detail": pmc_traffic(),
+            # north-star asks for the HBM fraction too: PMC bytes per launch / measured average launch duration vs 8 TB/s
+            "hbm": (lambda tb: None if tb is None else {"achieved": tb / (1e-3 * conv_ms / max(launches, 1)) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                                         "frac": tb / (1e-3 * conv_ms / max(launches, 1)) / 1e9 / 8000.0})(traffic_bytes_per_launch(pmc_traffic())),
             "achieved_executed": conv_exec * B * T / (conv_ms * 1e-3) / 1e12,
             "launches": launches,
             "avg_launch_us": 1e3 * conv_ms / max(launches, 1),
