@@ -1,0 +1,152 @@
+// kbench.hip — standalone A/B harness for the UNet conv kernels (no Python, no torch): old vs new kernel of every wide
+// shape of the full-size net at B = 1024 on the same random data; prints max |diff|, microseconds per launch
+// (interleaved rounds, HIP events) and executed TFLOP/s.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/kbench.hip -o tools/kbench
+#include "../edmp_amd/csrc/libedmp_hip.hip"
+#include "legacy_rcb_conv_r1.hip"
+
+#include <algorithm>
+#include <cmath>
+#include <random>
+
+using namespace edmp;
+
+static std::vector<float> rnd(size_t n, uint32_t seed, float scale) {
+    std::mt19937 g(seed);
+    std::uniform_real_distribution<float> d(-scale, scale);
+    std::vector<float> v(n);
+    for (auto& x : v) x = d(g);
+    return v;
+}
+template <class T>
+static T* up(const std::vector<T>& h) {
+    T* d = nullptr;
+    hipMalloc((void**)&d, h.size() * sizeof(T));
+    hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    return d;
+}
+static double max_abs_diff(const float* a_dev, const float* b_dev, size_t n, double* ref_max) {
+    std::vector<float> a(n), b(n);
+    hipMemcpy(a.data(), a_dev, n * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(b.data(), b_dev, n * 4, hipMemcpyDeviceToHost);
+    double m = 0, r = 0;
+    for (size_t i = 0; i < n; ++i) {
+        m = std::max(m, (double)std::fabs(a[i] - b[i]));
+        r = std::max(r, (double)std::fabs(a[i]));
+        if (std::isnan(a[i]) || std::isnan(b[i])) m = 1e30;
+    }
+    *ref_max = r;
+    return m;
+}
+
+template <class F>
+static float time_us(F&& f, int iters) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) f();
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return ms * 1000.f / iters;
+}
+
+template <int CG, int L, bool RES, int NW>
+static void run_wide(int B, int C1, int C2, bool with_res_add) {
+    const int Cout = CG * 8, Cin = C1 + C2;
+    const int ntap_store = RES ? 6 : 5;
+    const float wscale = 1.0f / std::sqrt((float)Cin * 5);
+    auto hW = rnd((size_t)ntap_store * Cout * Cin, 1, wscale * 1.7f);
+    auto hx1 = rnd((size_t)B * L * C1, 2, 1.5f);
+    auto hx2 = rnd((size_t)B * L * std::max(C2, 1), 3, 1.5f);
+    auto hb = rnd(Cout, 4, 0.1f), hg = rnd(Cout, 5, 1.0f), hbe = rnd(Cout, 6, 0.3f), htb = rnd(Cout, 7, 0.5f), hrb = rnd(Cout, 8, 0.1f);
+    auto hres = rnd((size_t)B * L * Cout, 9, 1.0f);
+    using Cf = WideCfg<CG, L, RES, NW>;
+    std::vector<float> hWf((size_t)(Cout / 32) * (Cin / 8) * Cf::NSLAB * 256);
+    pack_fragments(hW.data(), Cout, Cin, Cf::KT0, Cf::NTAP, RES, hWf.data());
+    float *W = up(hW), *Wf = up(hWf), *x1 = up(hx1), *x2 = up(hx2), *bias = up(hb), *gam = up(hg), *bet = up(hbe), *tb = up(htb), *rb = up(hrb), *res = up(hres);
+    float *d_old, *d_new, *r_old, *r_new;
+    const size_t nout = (size_t)B * L * Cout;
+    hipMalloc((void**)&d_old, nout * 4);
+    hipMalloc((void**)&d_new, nout * 4);
+    hipMalloc((void**)&r_old, nout * 4);
+    hipMalloc((void**)&r_new, nout * 4);
+    hipMemset(d_old, 0, nout * 4);
+    hipMemset(d_new, 0xff, nout * 4);
+    RcbP p{};
+    p.src1 = x1;
+    p.src2 = C2 ? x2 : nullptr;
+    p.C1 = C1;
+    p.C2 = C2;
+    p.W = W;
+    p.bias = bias;
+    p.gamma = gam;
+    p.beta = bet;
+    p.add_tb = with_res_add ? nullptr : tb;
+    p.add_res = with_res_add ? res : nullptr;
+    p.dst = d_old;
+    p.Cout = Cout;
+    p.B = B;
+    p.res_out = RES ? r_old : nullptr;
+    p.res_bias = RES ? rb : nullptr;
+    RcbP pn = p;
+    pn.W = Wf;
+    pn.dst = d_new;
+    pn.res_out = RES ? r_new : nullptr;
+    auto f_old = [&] { launch_rcb_t<CG, L, RES>(p, 0); };
+    auto f_new = [&] { launch_wide_t<CG, L, RES, NW>(pn, 0); };
+    f_old();
+    f_new();
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        printf("<%d,%d,%d,NW%d> C1=%d C2=%d: launch failed: %s\n", CG, L, (int)RES, NW, C1, C2, hipGetErrorString(e));
+        return;
+    }
+    double rm = 0, rm2 = 0;
+    const double d1 = max_abs_diff(d_old, d_new, nout, &rm);
+    const double d2 = RES ? max_abs_diff(r_old, r_new, nout, &rm2) : 0.0;
+    float t_old = 1e9f, t_new = 1e9f;
+    for (int round = 0; round < 5; ++round) {
+        t_old = std::min(t_old, time_us(f_old, 50));
+        t_new = std::min(t_new, time_us(f_new, 50));
+    }
+    // executed FLOPs: valid (out, in) position pairs
+    long pairs = 0;
+    for (int l = 0; l < L; ++l)
+        for (int lp = 0; lp < L; ++lp)
+            if (std::abs(l - lp) <= 2) ++pairs;
+    const double fl = 2.0 * B * (double)Cout * Cin * (pairs + (RES ? L : 0));
+    printf("<%2d,%d,%d,NW%d> Cin=%4d+%4d  max|d| %.2e (ref %.1f) res %.2e | old %7.2f us %6.1f TF | new %7.2f us %6.1f TF (%.3f of 157.3) | x%.3f\n", CG, L,
+           (int)RES, NW, C1, C2, d1, rm, d2, t_old, fl / t_old / 1e6, t_new, fl / t_new / 1e6, fl / t_new / 1e6 / 157.3, t_old / t_new);
+#ifdef EDMP_STAMPS
+    {
+        f_new();
+        hipDeviceSynchronize();
+        unsigned long long st[8][16];
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(edmp::g_stamps), sizeof(st));
+        printf("      stamps (shader cycles | 100MHz ticks): prologue %llu | K loop %llu | spill %llu | stats+store %llu | total %llu cyc = %.2f us\n", st[0][2] - st[0][0],
+               st[0][4] - st[0][2], st[0][6] - st[0][4], st[0][8] - st[0][6], st[0][8] - st[0][0], (st[0][9] - st[0][1]) / 100.0);
+    }
+#endif
+    for (float* q : {W, Wf, x1, x2, bias, gam, bet, tb, rb, res, d_old, d_new, r_old, r_new}) hipFree(q);
+}
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 1024;
+    run_wide<64, 2, false, 4>(B, 512, 0, true);
+    run_wide<64, 2, false, 8>(B, 512, 0, true);
+    run_wide<64, 2, true, 8>(B, 512, 512, false);
+    run_wide<64, 4, false, 8>(B, 512, 0, false);
+    run_wide<32, 4, false, 8>(B, 256, 0, true);
+    run_wide<64, 2, true, 4>(B, 512, 512, false);
+    run_wide<64, 4, false, 4>(B, 512, 0, false);
+    run_wide<64, 4, true, 4>(B, 256, 0, false);
+    run_wide<32, 4, false, 4>(B, 256, 0, true);
+    run_wide<32, 4, true, 4>(B, 512, 512, false);
+    run_wide<32, 7, false, 4>(B, 256, 0, true);
+    run_wide<32, 7, true, 4>(B, 128, 0, false);
+    return 0;
+}
