@@ -64,6 +64,7 @@ SIGNATURES = {
     "edmp_q_sample_dev": (_i, [_vp, _vp, _vp, _pi32, _i, _i, _i, _i, _i, _vp, _vp]),
     "edmp_prof_enable": (_i, [_vp, _i]),
     "edmp_prof_read": (_i, [_vp, _pd, C.POINTER(C.c_int64), _i]),
+    "edmp_prof_ops": (_i, [_vp, _i, C.POINTER(C.c_int), _pd, C.POINTER(C.c_int64), _pd, C.c_char_p]),
 }
 
 _lib = None

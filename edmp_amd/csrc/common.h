@@ -36,10 +36,18 @@ struct UNet;     // unet.hip
 struct Guide;    // guide.hip
 struct Sampler;  // sampler.hip
 
+// per-launch timing of the UNet layer program (HIP events on the context's stream around every conv-family launch),
+// switched on by edmp_prof_enable for bench.py's roofline pass; folded per program op by prof_fold()
 struct Prof {
     bool on = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // recorded, not yet read
+    struct Pend {
+        hipEvent_t a, b;
+        int op;
+    };
+    std::vector<Pend> pending;  // recorded, not yet read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    std::vector<double> op_ms;      // per program op
+    std::vector<int64_t> op_calls;
     double conv_ms = 0.0;
     int64_t conv_launches = 0;
 };
@@ -72,6 +80,7 @@ struct edmp_ctx {
 namespace edmp {
 
 void unet_destroy(UNet*);
+int prof_fold(edmp_ctx* ctx);  // unet.hip: read the pending event pairs into the per-op / total accumulators
 void guide_destroy(Guide*);
 void sampler_destroy(Sampler*);
 

@@ -426,8 +426,8 @@ extern "C" void edmp_ctx_destroy(edmp_ctx* ctx) {
     guide_destroy(ctx->guide);
     sampler_destroy(ctx->sampler);
     for (auto& e : ctx->prof.pending) {
-        (void)hipEventDestroy(e.first);
-        (void)hipEventDestroy(e.second);
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
     }
     for (auto& e : ctx->prof.pool) {
         (void)hipEventDestroy(e.first);
@@ -733,19 +733,14 @@ extern "C" int edmp_prof_read(edmp_ctx* ctx, double* conv_ms, int64_t* conv_laun
     EDMP_HIP_CHECK(hipSetDevice(ctx->device));
     EDMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     Prof& p = ctx->prof;
-    for (auto& e : p.pending) {
-        float ms = 0.f;
-        EDMP_HIP_CHECK(hipEventElapsedTime(&ms, e.first, e.second));
-        p.conv_ms += ms;
-        p.conv_launches += 1;
-        p.pool.push_back(e);
-    }
-    p.pending.clear();
+    if (int rc = prof_fold(ctx)) return rc;
     if (conv_ms) *conv_ms = p.conv_ms;
     if (conv_launches) *conv_launches = p.conv_launches;
     if (reset) {
         p.conv_ms = 0.0;
         p.conv_launches = 0;
+        std::fill(p.op_ms.begin(), p.op_ms.end(), 0.0);
+        std::fill(p.op_calls.begin(), p.op_calls.end(), (int64_t)0);
     }
     return EDMP_OK;
 }

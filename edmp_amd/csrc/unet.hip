@@ -175,7 +175,7 @@ struct BlkP {
     int B;
 };
 
-enum OpKind { OP_CONV = 0, OP_GN = 1, OP_RCB = 2, OP_BLK = 3 };
+enum OpKind { OP_CONV = 0, OP_GN = 1, OP_RCB = 2, OP_BLK = 3, OP_WRS = 4 };  // OP_WRS: down/up-sampling conv of a wide level on wide_conv_kernel
 struct Op {
     OpKind kind;
     ConvP cv;
@@ -183,11 +183,13 @@ struct Op {
     RcbP rc;
     BlkP bk;      // OP_BLK: a whole residual block
     int bk_variant;
-    int rc_L;     // OP_RCB: positions
+    int rc_L;     // OP_RCB / OP_WRS: input positions
+    int wrs_kind; // OP_WRS: WK_DOWN / WK_UP
     int rc_rows;  // OP_RCB: 0 = rcb_conv_kernel (wide levels), else rcb_rows_kernel variant
     int tb_off;   // GN: offset into the time-bias row, -1 if none
     int branch;   // 0 = main stream; 1 = fork point (record before this op); 2 = runs on the side stream; 3 = join (wait) before this op
-    double flops_nominal, flops_exec;  // CONV: per trajectory
+    double flops_nominal, flops_exec;  // per trajectory
+    char name[64];                     // kernel instance as rocprofv3 prints it (without the edmp:: prefix)
 };
 
 struct UNet {
@@ -1343,12 +1345,57 @@ static int launch_blk(const BlkP& p, int variant, hipStream_t s) {
 static int launch_rcb(const RcbP& p, int L, hipStream_t s) {
     const int cg = p.Cout / 8;
     const bool res = p.res_out != nullptr;
-    if (cg == 64 && L == 2) return res ? launch_wide_t<64, 2, true, 4>(p, s) : launch_wide_t<64, 2, false, 4>(p, s);
-    if (cg == 64 && L == 4) return res ? launch_wide_t<64, 4, true, 4>(p, s) : launch_wide_t<64, 4, false, 4>(p, s);
-    if (cg == 32 && L == 4) return res ? launch_wide_t<32, 4, true, 4>(p, s) : launch_wide_t<32, 4, false, 4>(p, s);
-    if (cg == 32 && L == 7) return res ? launch_wide_t<32, 7, true, 4>(p, s) : launch_wide_t<32, 7, false, 4>(p, s);
+    if (cg == 64 && L == 2) return res ? launch_wide_t<WK_K5, 64, 2, true, 4>(p, s) : launch_wide_t<WK_K5, 64, 2, false, 4>(p, s);
+    if (cg == 64 && L == 4) return res ? launch_wide_t<WK_K5, 64, 4, true, 4>(p, s) : launch_wide_t<WK_K5, 64, 4, false, 4>(p, s);
+    if (cg == 32 && L == 4) return res ? launch_wide_t<WK_K5, 32, 4, true, 4>(p, s) : launch_wide_t<WK_K5, 32, 4, false, 4>(p, s);
+    if (cg == 32 && L == 7) return res ? launch_wide_t<WK_K5, 32, 7, true, 4>(p, s) : launch_wide_t<WK_K5, 32, 7, false, 4>(p, s);
     set_error("no fused conv+GroupNorm kernel for Cout=%d L=%d", p.Cout, L);
     return EDMP_ERR_STATE;
+}
+
+// down/up-sampling convs of the wide levels (no GroupNorm behind them) on the position-tile kernel
+static bool wrs_supported(int cout, int cin, int Lin, bool transposed) {
+    const int cg = cout / 8;
+    if (cout % 8 != 0 || cin % 32 != 0 || !(cg == 32 || cg == 64)) return false;
+    return transposed ? (Lin == 2 || Lin == 4) : (Lin == 4 || Lin == 7);
+}
+static int launch_wrs(const RcbP& p, int kind, int Lin, hipStream_t s) {
+    const int cg = p.Cout / 8;
+    if (kind == WK_DOWN) {
+        if (cg == 64 && Lin == 4) return launch_wide_t<WK_DOWN, 64, 4, false, 4>(p, s);
+        if (cg == 32 && Lin == 4) return launch_wide_t<WK_DOWN, 32, 4, false, 4>(p, s);
+        if (cg == 64 && Lin == 7) return launch_wide_t<WK_DOWN, 64, 7, false, 4>(p, s);
+        if (cg == 32 && Lin == 7) return launch_wide_t<WK_DOWN, 32, 7, false, 4>(p, s);
+    } else {
+        if (cg == 64 && Lin == 2) return launch_wide_t<WK_UP, 64, 2, false, 4>(p, s);
+        if (cg == 32 && Lin == 2) return launch_wide_t<WK_UP, 32, 2, false, 4>(p, s);
+        if (cg == 64 && Lin == 4) return launch_wide_t<WK_UP, 64, 4, false, 4>(p, s);
+        if (cg == 32 && Lin == 4) return launch_wide_t<WK_UP, 32, 4, false, 4>(p, s);
+    }
+    set_error("no wide resampling kernel for kind=%d Cout=%d Lin=%d", kind, p.Cout, Lin);
+    return EDMP_ERR_STATE;
+}
+
+// kernel instance an op launches, spelled as rocprofv3's kernel trace prints it (minus the edmp:: prefix): lets
+// bench.py's per-kernel table be checked line by line against profiles/*_kernel_stats.csv
+static void op_kernel_name(const Op& op, char* out) {
+    static const char* rows_names[] = {"", "rcb_rows_kernel<32, 50, 2, 8>", "rcb_rows_kernel<32, 50, 2, 32>", "rcb_rows_kernel<32, 25, 5, 32>",
+                                       "rcb_rows_kernel<64, 25, 5, 32>", "rcb_rows_kernel<64, 13, 8, 32>", "rcb_rows_kernel<64, 7, 9, 32>"};
+    static const char* blk_names[] = {"", "rcb_block_kernel<32, 50, 2, 8, true>", "", "rcb_block_kernel<32, 50, 2, 32, true>", "rcb_block_kernel<32, 50, 2, 32, false>",
+                                      "rcb_block_kernel<64, 25, 4, 16, true>", "rcb_block_kernel<64, 25, 4, 16, false>", "rcb_block_kernel<64, 13, 4, 32, true>",
+                                      "rcb_block_kernel<64, 13, 4, 32, false>", "rcb_block_kernel<32, 25, 4, 32, true>", "rcb_block_kernel<32, 25, 4, 32, false>"};
+    if (op.kind == OP_RCB && op.rc_rows) snprintf(out, 64, "%s", rows_names[op.rc_rows]);
+    else if (op.kind == OP_RCB) snprintf(out, 64, "wide_conv_kernel<0, %d, %d, %s, 4>", op.rc.Cout / 8, op.rc_L, op.rc.res_out ? "true" : "false");
+    else if (op.kind == OP_WRS) snprintf(out, 64, "wide_conv_kernel<%d, %d, %d, false, 4>", op.wrs_kind, op.rc.Cout / 8, op.rc_L);
+    else if (op.kind == OP_BLK) snprintf(out, 64, "%s", blk_names[op.bk_variant]);
+    else if (op.kind == OP_CONV) {
+        const int kc = pick_kc(op.cv);
+        if (op.cv.Cout % 64 == 0) snprintf(out, 64, "conv_mfma_kernel<64, 64, %d>", kc);
+        else snprintf(out, 64, "conv_mfma_kernel<128, 32, %d>", kc >= 32 ? 32 : kc);
+    } else {
+        const int n = (op.gn.C / 8) * op.gn.L;
+        snprintf(out, 64, "gn_mish_kernel<%d>", n <= 128 ? 2 : n <= 256 ? 4 : 8);
+    }
 }
 
 void unet_destroy(UNet* u) {
@@ -1396,6 +1443,17 @@ struct Packer {
             }
         size_t o = add((size_t)(cout / 32) * (cinp / 8) * nslab * 256);
         pack_fragments(tmp.data(), cout, cinp, kt0, ntap, wres != nullptr, &host[o]);
+        return o;
+    }
+    // strided Conv1d k3 (Cout, Cin, 3) or ConvTranspose1d k4 (Cin, Cout, 4) of a wide level -> fragment stream, slot = tap
+    size_t resample_frag(const float* w, int cin, int cout, int k, bool transposed) {
+        std::vector<float> tmp((size_t)6 * cout * cin, 0.0f);
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int t = 0; t < k; ++t)
+                    tmp[((size_t)t * cout + co) * cin + ci] = transposed ? w[((size_t)ci * cout + co) * k + t] : w[((size_t)co * cin + ci) * k + t];
+        size_t o = add((size_t)(cout / 32) * (cin / 8) * k * 256);
+        pack_fragments(tmp.data(), cout, cin, 0, k, false, &host[o]);
         return o;
     }
     size_t vec(const float* v, int n) {
@@ -1527,6 +1585,29 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
         // nominal FLOPs: what torch executes: conv 2*Lout*Cout*Cin*k ; convT 2*Lin*Cin*Cout*k (uncropped)
         o.fn = tr ? 2.0 * a.L * cin_true * Cout * k : 2.0 * Lout * Cout * (double)cin_true * k;
         o.fe = 2.0 * (double)valid_pairs(a.L, Lout, k, stride, pad, tr) * Cout * (double)(o.C1 + o.C2);
+        pops.push_back(o);
+        return TH{o.dst, Cout, Lout};
+    };
+    auto emit_wrs = [&](TH a, size_t w, size_t b, int Cout, int kind, int k, int Lout) {
+        POp o{};
+        o.kind = OP_WRS;
+        o.src1 = a.buf;
+        o.C1 = a.C;
+        o.src2 = -1;
+        o.C2 = 0;
+        o.Lin = a.L;
+        o.Lout = Lout;
+        o.ntaps = k;
+        o.transposed = (kind == WK_UP);
+        o.Cout = Cout;
+        o.w = w;
+        o.b = b;
+        o.dst = pool.get();
+        o.res_out = -1;
+        o.blk = kind;
+        const bool tr = kind == WK_UP;
+        o.fn = tr ? 2.0 * a.L * (double)a.C * Cout * k : 2.0 * Lout * Cout * (double)a.C * k;
+        o.fe = 2.0 * (double)valid_pairs(a.L, Lout, k, 2, 1, tr) * Cout * (double)a.C;
         pops.push_back(o);
         return TH{o.dst, Cout, Lout};
     };
@@ -1680,10 +1761,16 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
         pool.put(a.buf);
         skips.push_back(b);
         if (i != nd - 1) {
-            size_t w = pk.conv(params + inv.down_w[i].off, dm[i + 1], dm[i + 1], 3, dm[i + 1]);
-            size_t bb = pk.vec(params + inv.down_b[i].off, dm[i + 1]);
             int Lout = (b.L - 1) / 2 + 1;
-            x = emit_conv(b, nullptr, dm[i + 1], w, bb, dm[i + 1], 3, 2, 1, false, Lout);
+            if (use_fused && wrs_supported(dm[i + 1], b.C, b.L, false)) {
+                size_t w = pk.resample_frag(params + inv.down_w[i].off, dm[i + 1], dm[i + 1], 3, false);
+                size_t bb = pk.vec(params + inv.down_b[i].off, dm[i + 1]);
+                x = emit_wrs(b, w, bb, dm[i + 1], WK_DOWN, 3, Lout);
+            } else {
+                size_t w = pk.conv(params + inv.down_w[i].off, dm[i + 1], dm[i + 1], 3, dm[i + 1]);
+                size_t bb = pk.vec(params + inv.down_b[i].off, dm[i + 1]);
+                x = emit_conv(b, nullptr, dm[i + 1], w, bb, dm[i + 1], 3, 2, 1, false, Lout);
+            }
         } else {
             x = b;
         }
@@ -1708,11 +1795,17 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
         pool.put(sk.buf);
         TH b = emit_rcb(a, nullptr);
         pool.put(a.buf);
-        size_t w = pk.convT(params + inv.up_w[j].off, dm[i - 1], dm[i - 1], 4);
-        size_t bb = pk.vec(params + inv.up_b[j].off, dm[i - 1]);
         int Lout = 2 * b.L;
         if (Lout == 8 || Lout == 14 || Lout == 26) Lout -= 1;  // crop rule, temporalunet.py:70-71
-        x = emit_conv(b, nullptr, dm[i - 1], w, bb, dm[i - 1], 4, 2, 1, true, Lout);
+        if (use_fused && wrs_supported(dm[i - 1], b.C, b.L, true)) {
+            size_t w = pk.resample_frag(params + inv.up_w[j].off, dm[i - 1], dm[i - 1], 4, true);
+            size_t bb = pk.vec(params + inv.up_b[j].off, dm[i - 1]);
+            x = emit_wrs(b, w, bb, dm[i - 1], WK_UP, 4, Lout);
+        } else {
+            size_t w = pk.convT(params + inv.up_w[j].off, dm[i - 1], dm[i - 1], 4);
+            size_t bb = pk.vec(params + inv.up_b[j].off, dm[i - 1]);
+            x = emit_conv(b, nullptr, dm[i - 1], w, bb, dm[i - 1], 4, 2, 1, true, Lout);
+        }
         pool.put(b.buf);
         tapr.push_back({200 + j, x.buf, x.C, x.L});
         pool.pin(x.buf);
@@ -1747,7 +1840,7 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
     // allocate
     size_t max_lc = (size_t)N * CP0;
     for (auto& o : pops)
-        if (o.kind == OP_CONV || o.kind == OP_RCB || o.kind == OP_BLK) max_lc = std::max(max_lc, (size_t)o.Lout * o.Cout);
+        if (o.kind == OP_CONV || o.kind == OP_RCB || o.kind == OP_BLK || o.kind == OP_WRS) max_lc = std::max(max_lc, (size_t)o.Lout * o.Cout);
     u->buf_cap = max_lc * (size_t)max_batch;
     if (hipMalloc((void**)&u->wpack, pk.host.size() * sizeof(float)) != hipSuccess) {
         unet_destroy(u);
@@ -1822,6 +1915,22 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
             op.flops_exec = o.fe;
             u->flops_nominal += o.fn;
             u->flops_exec += o.fe;
+        } else if (o.kind == OP_WRS) {
+            RcbP& c = op.rc;
+            c.src1 = u->bufs[o.src1];
+            c.src2 = nullptr;
+            c.C1 = o.C1;
+            c.C2 = 0;
+            c.W = u->wpack + o.w;
+            c.bias = u->wpack + o.b;
+            c.dst = u->bufs[o.dst];
+            c.Cout = o.Cout;
+            op.rc_L = o.Lin;
+            op.wrs_kind = o.blk;
+            op.flops_nominal = o.fn;
+            op.flops_exec = o.fe;
+            u->flops_nominal += o.fn;
+            u->flops_exec += o.fe;
         } else if (o.kind == OP_RCB) {
             RcbP& c = op.rc;
             c.src1 = u->bufs[o.src1];
@@ -1856,6 +1965,7 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
             g.C = o.C;
             op.tb_off = o.tb_off;
         }
+        op_kernel_name(op, op.name);
         u->prog.push_back(op);
     }
     u->flops_nominal += head_flops;
@@ -1878,10 +1988,11 @@ int unet_run_program(edmp_ctx* ctx, int B, int t) {
     EDMP_REQUIRE(u, "edmp_unet_load has not been called");
     EDMP_REQUIRE(B >= 1 && B <= u->max_batch, "batch %d outside 1..max_batch=%d", B, u->max_batch);
     EDMP_REQUIRE(t >= 1 && t <= u->desc.T, "t=%d outside 1..T=%d", t, u->desc.T);
-    hipStream_t s = ctx->stream;
     const float* trow = u->tbias + (size_t)(t - 1) * u->tb_stride;
     Prof& pf = ctx->prof;
+    int op_index = -1;
     for (const Op& op : u->prog) {
+        ++op_index;
         hipStream_t s = ctx->stream;
         if (op.branch == 1) {
             EDMP_HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -1891,78 +2002,75 @@ int unet_run_program(edmp_ctx* ctx, int B, int t) {
         } else if (op.branch == 3) {
             EDMP_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         }
+        Prof::Pend ev{nullptr, nullptr, op_index};
+        const bool timed = pf.on && op.kind != OP_GN;
+        if (timed) {
+            if (!pf.pool.empty()) {
+                ev.a = pf.pool.back().first;
+                ev.b = pf.pool.back().second;
+                pf.pool.pop_back();
+            } else {
+                EDMP_HIP_CHECK(hipEventCreate(&ev.a));
+                EDMP_HIP_CHECK(hipEventCreate(&ev.b));
+            }
+            EDMP_HIP_CHECK(hipEventRecord(ev.a, s));
+        }
+        int rc = EDMP_OK;
         if (op.kind == OP_BLK) {
             BlkP p = op.bk;
             p.B = B;
             p.tb = trow + op.tb_off;
-            std::pair<hipEvent_t, hipEvent_t> ev{};
-            if (pf.on) {
-                if (!pf.pool.empty()) {
-                    ev = pf.pool.back();
-                    pf.pool.pop_back();
-                } else {
-                    EDMP_HIP_CHECK(hipEventCreate(&ev.first));
-                    EDMP_HIP_CHECK(hipEventCreate(&ev.second));
-                }
-                EDMP_HIP_CHECK(hipEventRecord(ev.first, s));
-            }
-            int rc = launch_blk(p, op.bk_variant, s);
-            if (rc) return rc;
-            if (pf.on) {
-                EDMP_HIP_CHECK(hipEventRecord(ev.second, s));
-                pf.pending.push_back(ev);
-            }
+            rc = launch_blk(p, op.bk_variant, s);
         } else if (op.kind == OP_RCB) {
             RcbP p = op.rc;
             p.B = B;
             p.add_tb = op.tb_off >= 0 ? trow + op.tb_off : nullptr;
             EDMP_REQUIRE(!(p.add_tb && p.add_res), "fused conv block: a launch adds the time bias (conv1) or the residual (conv2), not both");
-            std::pair<hipEvent_t, hipEvent_t> ev{};
-            if (pf.on) {
-                if (!pf.pool.empty()) {
-                    ev = pf.pool.back();
-                    pf.pool.pop_back();
-                } else {
-                    EDMP_HIP_CHECK(hipEventCreate(&ev.first));
-                    EDMP_HIP_CHECK(hipEventCreate(&ev.second));
-                }
-                EDMP_HIP_CHECK(hipEventRecord(ev.first, s));
-            }
-            int rc = op.rc_rows ? launch_rows(p, op.rc_rows, s) : launch_rcb(p, op.rc_L, s);
-            if (rc) return rc;
-            if (pf.on) {
-                EDMP_HIP_CHECK(hipEventRecord(ev.second, s));
-                pf.pending.push_back(ev);
-            }
+            rc = op.rc_rows ? launch_rows(p, op.rc_rows, s) : launch_rcb(p, op.rc_L, s);
+        } else if (op.kind == OP_WRS) {
+            RcbP p = op.rc;
+            p.B = B;
+            rc = launch_wrs(p, op.wrs_kind, op.rc_L, s);
         } else if (op.kind == OP_CONV) {
             ConvP p = op.cv;
             p.B = B;
-            if (pf.on) {
-                std::pair<hipEvent_t, hipEvent_t> ev;
-                if (!pf.pool.empty()) {
-                    ev = pf.pool.back();
-                    pf.pool.pop_back();
-                } else {
-                    EDMP_HIP_CHECK(hipEventCreate(&ev.first));
-                    EDMP_HIP_CHECK(hipEventCreate(&ev.second));
-                }
-                EDMP_HIP_CHECK(hipEventRecord(ev.first, s));
-                launch_conv(p, s);
-                EDMP_HIP_CHECK(hipEventRecord(ev.second, s));
-                pf.pending.push_back(ev);
-            } else {
-                launch_conv(p, s);
-            }
-            if (op.branch == 2) EDMP_HIP_CHECK(hipEventRecord(ctx->ev_join, s));
+            launch_conv(p, s);
         } else {
             GnP g = op.gn;
             g.B = B;
             g.add_tbias = op.tb_off >= 0 ? trow + op.tb_off : nullptr;
-            int rc = launch_gn(g, s);
-            if (rc) return rc;
+            rc = launch_gn(g, s);
         }
+        if (rc) return rc;
+        if (timed) {
+            EDMP_HIP_CHECK(hipEventRecord(ev.b, s));
+            pf.pending.push_back(ev);
+        }
+        if (op.kind == OP_CONV && op.branch == 2) EDMP_HIP_CHECK(hipEventRecord(ctx->ev_join, s));
     }
     EDMP_HIP_CHECK(hipGetLastError());
+    return EDMP_OK;
+}
+
+int prof_fold(edmp_ctx* ctx) {
+    Prof& p = ctx->prof;
+    const size_t nops = ctx->unet ? ctx->unet->prog.size() : 0;
+    if (p.op_ms.size() != nops) {
+        p.op_ms.assign(nops, 0.0);
+        p.op_calls.assign(nops, 0);
+    }
+    for (auto& e : p.pending) {
+        float ms = 0.f;
+        EDMP_HIP_CHECK(hipEventElapsedTime(&ms, e.a, e.b));
+        p.conv_ms += ms;
+        p.conv_launches += 1;
+        if (e.op >= 0 && (size_t)e.op < nops) {
+            p.op_ms[e.op] += ms;
+            p.op_calls[e.op] += 1;
+        }
+        p.pool.push_back({e.a, e.b});
+    }
+    p.pending.clear();
     return EDMP_OK;
 }
 
@@ -2010,6 +2118,26 @@ extern "C" int edmp_unet_flops(edmp_ctx* ctx, double* nominal, double* executed)
     EDMP_REQUIRE(ctx && ctx->unet, "no model loaded");
     if (nominal) *nominal = ctx->unet->flops_nominal;
     if (executed) *executed = ctx->unet->flops_exec;
+    return EDMP_OK;
+}
+
+extern "C" int edmp_prof_ops(edmp_ctx* ctx, int cap, int* n_ops, double* ms, int64_t* calls, double* flops_exec, char* names) {
+    EDMP_REQUIRE(ctx && ctx->unet && n_ops, "edmp_prof_ops: null argument / no model");
+    EDMP_HIP_CHECK(hipSetDevice(ctx->device));
+    EDMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (int rc = prof_fold(ctx)) return rc;
+    const int n = (int)ctx->unet->prog.size();
+    *n_ops = n;
+    for (int i = 0; i < n && i < cap; ++i) {
+        const Op& op = ctx->unet->prog[i];
+        if (ms) ms[i] = ctx->prof.op_ms[i];
+        if (calls) calls[i] = ctx->prof.op_calls[i];
+        if (flops_exec) flops_exec[i] = op.flops_exec;
+        if (names) {
+            strncpy(names + (size_t)i * 64, op.name, 63);
+            names[(size_t)i * 64 + 63] = 0;
+        }
+    }
     return EDMP_OK;
 }
 

@@ -41,46 +41,60 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int CG, int L, bool RES, int NW>
+// which convolution the position-tile kernel computes (tap slot of the (output position l, input position lp) pair):
+//   WK_K5   Conv1d k5 s1 p2 + GroupNorm + Mish + add (Conv1dBlock, blocks.py:22-28):      tap = lp - l + 2
+//   WK_DOWN Conv1d k3 s2 p1 + bias (DownSampler's last layer, blocks.py:213):              tap = lp - 2l + 1
+//   WK_UP   ConvTranspose1d k4 s2 p1 + bias, cropped (UpSampler, blocks.py:251; temporalunet.py:70-71): tap = l + 1 - 2lp
+enum WideKind { WK_K5 = 0, WK_DOWN = 1, WK_UP = 2 };
+
+template <int KIND, int CG, int LIN, bool RES, int NW>
 struct WideCfg {
+    static constexpr int L = LIN;                    // input positions (all staged per chunk)
+    static constexpr int LOUT = (KIND == WK_K5) ? LIN : (KIND == WK_DOWN) ? (LIN - 1) / 2 + 1 : ((2 * LIN == 8 || 2 * LIN == 14 || 2 * LIN == 26) ? 2 * LIN - 1 : 2 * LIN);
+    static constexpr bool GN = (KIND == WK_K5);      // GroupNorm + Mish + add epilogue (else: + bias)
     static constexpr int S = CG / 32;               // 32-channel output slabs per group
     static constexpr int KSPLIT = NW / S;            // waves sharing a slab, each with its own K slice
     static constexpr int KC = (8 * KSPLIT > 32) ? 8 * KSPLIT : 32;  // channels per staged chunk
     static constexpr int QW = KC / 8 / KSPLIT;       // 8-channel K groups per wave per chunk
     static constexpr int LDK = KC + 4;
-    static constexpr int KT0 = (L == 2) ? 1 : 0;     // first tap that can be valid
-    static constexpr int NTAP = (L == 2) ? 3 : 5;    // taps that can be valid
+    static constexpr int KT0 = (KIND == WK_K5 && LIN == 2) ? 1 : 0;  // first tap that can be valid
+    static constexpr int NTAP = (KIND == WK_K5) ? ((LIN == 2) ? 3 : 5) : (KIND == WK_DOWN) ? 3 : 4;  // taps that can be valid
     static constexpr int NSLAB = NTAP + (RES ? 1 : 0);
+    // weight slot of the pair (output tile l, input position lp), -1 if the tap does not exist
+    static constexpr int slot(int l, int lp) {
+        const int t = (KIND == WK_K5) ? lp - l + 2 - KT0 : (KIND == WK_DOWN) ? lp - 2 * l + 1 : l + 1 - 2 * lp;
+        return (t >= 0 && t < NTAP) ? t : -1;
+    }
     static constexpr int A_FL = L * 32 * LDK;        // floats per activation stage
     static constexpr int NTH = NW * 64;
     static constexpr int A_F4 = L * 32 * (KC / 4);   // float4 items per stage
     static constexpr int NA = (A_F4 + NTH - 1) / NTH;
     static constexpr int NBL = QW * NSLAB;           // weight-fragment loads per wave per chunk
-    static constexpr int YS = L * CG + 4;
+    static constexpr int YS = LOUT * CG + 4;
     static constexpr int NP = KSPLIT;                // partial tiles per output element
-    static constexpr int NF4 = L * CG / 32;          // float4 per thread in the final pass (256 threads)
-    // MFMA groups (4 MFMAs each) per chunk per wave
-    static constexpr int groups_per_q() {
-        int n = 0;
-        for (int lp = 0; lp < L; ++lp) {
-            for (int l = (lp - 2 > 0 ? lp - 2 : 0); l <= (lp + 2 < L - 1 ? lp + 2 : L - 1); ++l) ++n;
-            if (RES) ++n;
-        }
-        return n;
-    }
-    static constexpr int GPQ = groups_per_q();
-    static constexpr int NG = QW * GPQ;
-    // index (within one K group q) of the first MFMA group of input position lp
+    static constexpr int NF4 = LOUT * CG / 32;       // float4 per thread in the final pass (256 threads)
+    // number of MFMA groups (4 MFMAs each) of input positions [0, lp) within one K group
     static constexpr int gbase(int lp) {
         int n = 0;
         for (int x = 0; x < lp; ++x) {
-            n += (x + 2 < L - 1 ? x + 2 : L - 1) - (x - 2 > 0 ? x - 2 : 0) + 1;
+            for (int l = 0; l < LOUT; ++l)
+                if (slot(l, x) >= 0) ++n;
             if (RES) ++n;
         }
         return n;
     }
+    // index of the group (l, lp) among the groups of input position lp
+    static constexpr int gofs(int l, int lp) {
+        int n = 0;
+        for (int x = 0; x < l; ++x)
+            if (slot(x, lp) >= 0) ++n;
+        return n;
+    }
+    static constexpr int GPQ = gbase(L);
+    static constexpr int NG = QW * GPQ;
     static constexpr int NLOAD = NA + NBL;
     static constexpr int LPG = (NLOAD + (NG - NA) - 1) / (NG - NA);  // loads per group so that they finish before the commits start
+    static constexpr long valid_pairs() { return (long)GPQ - (RES ? L : 0); }
     static constexpr size_t lds_bytes() {
         size_t a = 3 * (size_t)A_FL * sizeof(float);
         size_t y = (size_t)NP * 32 * (size_t)YS * sizeof(float);
@@ -88,12 +102,15 @@ struct WideCfg {
     }
     static_assert(NG > NA, "more MFMA groups than staging items");
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert(!RES || KIND == WK_K5, "the folded residual 1x1 conv belongs to a Conv1dBlock");
+    static_assert((LOUT * CG) % 32 == 0, "final pass: whole float4 columns per thread");
 };
 
 // weight-fragment stream of one conv in HBM: [Cout/32][Cin/8][NSLAB][64 lanes][4] floats (Packer::conv_frag)
-template <int CG, int L, bool RES, int NW>
+template <int KIND, int CG, int LIN, bool RES, int NW>
 __global__ __launch_bounds__(NW * 64) void wide_conv_kernel(RcbP p) {
-    using Cf = WideCfg<CG, L, RES, NW>;
+    using Cf = WideCfg<KIND, CG, LIN, RES, NW>;
+    constexpr int L = Cf::L, LOUT = Cf::LOUT;
     constexpr int S = Cf::S, KC = Cf::KC, QW = Cf::QW, LDK = Cf::LDK, KT0 = Cf::KT0, NTAP = Cf::NTAP, NSLAB = Cf::NSLAB;
     constexpr int A_FL = Cf::A_FL, NTH = Cf::NTH, A_F4 = Cf::A_F4, NA = Cf::NA, YS = Cf::YS, NP = Cf::NP;
     constexpr int NG = Cf::NG, LPG = Cf::LPG, NBL = Cf::NBL;
@@ -125,10 +142,10 @@ __global__ __launch_bounds__(NW * 64) void wide_conv_kernel(RcbP p) {
     // ---- weight fragment stream of this wave
     const float* wb = p.W + ((size_t)(blockIdx.x * S + s) * NKG) * (NSLAB * 256) + lane * 4;
 
-    f32x16 acc[L];
+    f32x16 acc[LOUT];
     f32x16 racc[RES ? L : 1];
 #pragma unroll
-    for (int t = 0; t < L; ++t)
+    for (int t = 0; t < LOUT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
     if constexpr (RES) {
@@ -214,21 +231,22 @@ __global__ __launch_bounds__(NW * 64) void wide_conv_kernel(RcbP p) {
             constexpr int q = decltype(qc)::value;
             static_for<0, L>([&](auto lpc) __attribute__((always_inline)) {
                 constexpr int lp = decltype(lpc)::value;
-                constexpr int l_lo = (lp - 2 > 0 ? lp - 2 : 0), l_hi = (lp + 2 < L - 1 ? lp + 2 : L - 1);
                 // next A fragment: (lp+1, q) | (0, q+1) | first fragment of the next chunk
                 const float* an_p = (lp + 1 < L) ? st + frag + (lp + 1) * (32 * LDK) + 8 * q
                                     : (q + 1 < QW) ? st + frag + 8 * (q + 1)
                                                    : stn + frag;
                 const float4 an = *reinterpret_cast<const float4*>(an_p);
-                static_for<l_lo, l_hi + 1>([&](auto lc) __attribute__((always_inline)) {
+                static_for<0, LOUT>([&](auto lc) __attribute__((always_inline)) {
                     constexpr int l = decltype(lc)::value;
-                    side(std::integral_constant<int, q * Cf::GPQ + Cf::gbase(lp) + l - l_lo>{});
-                    __builtin_amdgcn_sched_barrier(0);  // memory work strictly BETWEEN the four-MFMA chains, never inside one
-                    EDMP_W_MFMA4(acc[l], bc[q][lp - l + 2 - KT0])
-                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (Cf::slot(l, lp) >= 0) {
+                        side(std::integral_constant<int, q * Cf::GPQ + Cf::gbase(lp) + Cf::gofs(l, lp)>{});
+                        __builtin_amdgcn_sched_barrier(0);  // memory work strictly BETWEEN the four-MFMA chains, never inside one
+                        EDMP_W_MFMA4(acc[l], bc[q][Cf::slot(l, lp)])
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 });
                 if constexpr (RES) {
-                    side(std::integral_constant<int, q * Cf::GPQ + Cf::gbase(lp) + l_hi - l_lo + 1>{});
+                    side(std::integral_constant<int, q * Cf::GPQ + Cf::gbase(lp + 1) - 1>{});
                     __builtin_amdgcn_sched_barrier(0);
                     EDMP_W_MFMA4(racc[lp], bc[q][NTAP])
                     __builtin_amdgcn_sched_barrier(0);
@@ -256,24 +274,28 @@ __global__ __launch_bounds__(NW * 64) void wide_conv_kernel(RcbP p) {
 #undef EDMP_W_MFMA4
     EDMP_STAMP(0, 2)
 
-    // ---- epilogue: K-slice partial tiles (+bias in slice 0) -> LDS, per-sample statistics over the whole group,
-    //      normalise, Mish, add, store (as rcb_conv_kernel's; the closing barrier of the last step freed the stages)
+    // ---- epilogue: K-slice partial tiles (+bias in slice 0) -> LDS; then per thread (sample row, 8-column part) the
+    //      partials are summed and, for a Conv1dBlock, the per-sample statistics over the whole group are reduced,
+    //      normalise, Mish, add; float4 stores (the closing barrier of the last step freed the stages)
     float* Y = lds;  // [NP][32][YS]
     const int et = tid & 255;  // the final pass runs on the first 256 threads
     const int erow = et >> 3, epart = et & 7;
     const int eb = min(b0 + erow, p.B - 1);
     constexpr int NF4 = Cf::NF4;
-    float4 g4[NF4], be4[NF4], ad4[NF4];
-    if (NW == 4 || tid < 256) {
+    constexpr bool GN = Cf::GN;
+    float4 g4[GN ? NF4 : 1], be4[GN ? NF4 : 1], ad4[GN ? NF4 : 1];
+    if constexpr (GN) {
+        if (NW == 4 || tid < 256) {
 #pragma unroll
-        for (int i = 0; i < NF4; ++i) {
-            const int col = 4 * (epart + 8 * i);
-            const int l = col / CG, ch = co0 + col % CG;
-            g4[i] = *reinterpret_cast<const float4*>(p.gamma + ch);
-            be4[i] = *reinterpret_cast<const float4*>(p.beta + ch);
-            ad4[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // one addend per launch: conv1 the time bias, conv2 the residual
-            if (p.add_res) ad4[i] = *reinterpret_cast<const float4*>(p.add_res + ((size_t)eb * L + l) * p.Cout + ch);
-            else if (p.add_tb) ad4[i] = *reinterpret_cast<const float4*>(p.add_tb + ch);
+            for (int i = 0; i < NF4; ++i) {
+                const int col = 4 * (epart + 8 * i);
+                const int l = col / CG, ch = co0 + col % CG;
+                g4[i] = *reinterpret_cast<const float4*>(p.gamma + ch);
+                be4[i] = *reinterpret_cast<const float4*>(p.beta + ch);
+                ad4[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // one addend per launch: conv1 the time bias, conv2 the residual
+                if (p.add_res) ad4[i] = *reinterpret_cast<const float4*>(p.add_res + ((size_t)eb * LOUT + l) * p.Cout + ch);
+                else if (p.add_tb) ad4[i] = *reinterpret_cast<const float4*>(p.add_tb + ch);
+            }
         }
     }
     float* Yw = Y + ks * (32 * YS) + s * 32 + (lane & 31);
@@ -303,7 +325,7 @@ __global__ __launch_bounds__(NW * 64) void wide_conv_kernel(RcbP p) {
         __syncthreads();
     }
 #pragma unroll
-    for (int l = 0; l < L; ++l)
+    for (int l = 0; l < LOUT; ++l)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -325,33 +347,42 @@ __global__ __launch_bounds__(NW * 64) void wide_conv_kernel(RcbP p) {
             }
             sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
-        sum += __shfl_xor(sum, 1, 64);
-        sum += __shfl_xor(sum, 2, 64);
-        sum += __shfl_xor(sum, 4, 64);
-        constexpr float inv_n = 1.0f / (float)(L * CG);
-        const float mean = sum * inv_n;
-        float sq = 0.f;
+        if constexpr (GN) {
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            sum += __shfl_xor(sum, 4, 64);
+            constexpr float inv_n = 1.0f / (float)(LOUT * CG);
+            const float mean = sum * inv_n;
+            float sq = 0.f;
 #pragma unroll
-        for (int i = 0; i < NF4; ++i) {
-            const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
-            sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-        }
-        sq += __shfl_xor(sq, 1, 64);
-        sq += __shfl_xor(sq, 2, 64);
-        sq += __shfl_xor(sq, 4, 64);
-        const float rstd = 1.0f / sqrtf(sq * inv_n + 1e-5f);
-        if (b < p.B) {
+            for (int i = 0; i < NF4; ++i) {
+                const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+                sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+            sq += __shfl_xor(sq, 1, 64);
+            sq += __shfl_xor(sq, 2, 64);
+            sq += __shfl_xor(sq, 4, 64);
+            const float rstd = 1.0f / sqrtf(sq * inv_n + 1e-5f);
+            if (b < p.B) {
+#pragma unroll
+                for (int i = 0; i < NF4; ++i) {
+                    const int col = 4 * (epart + 8 * i);
+                    const int l = col / CG, ch = co0 + col % CG;
+                    const float s0 = rstd * g4[i].x, s1 = rstd * g4[i].y, s2 = rstd * g4[i].z, s3 = rstd * g4[i].w;
+                    float4 o;
+                    o.x = mish_fast(v[i].x * s0 + (be4[i].x - s0 * mean)) + ad4[i].x;
+                    o.y = mish_fast(v[i].y * s1 + (be4[i].y - s1 * mean)) + ad4[i].y;
+                    o.z = mish_fast(v[i].z * s2 + (be4[i].z - s2 * mean)) + ad4[i].z;
+                    o.w = mish_fast(v[i].w * s3 + (be4[i].w - s3 * mean)) + ad4[i].w;
+                    *reinterpret_cast<float4*>(p.dst + ((size_t)b * LOUT + l) * p.Cout + ch) = o;
+                }
+            }
+        } else if (b < p.B) {
 #pragma unroll
             for (int i = 0; i < NF4; ++i) {
                 const int col = 4 * (epart + 8 * i);
                 const int l = col / CG, ch = co0 + col % CG;
-                const float s0 = rstd * g4[i].x, s1 = rstd * g4[i].y, s2 = rstd * g4[i].z, s3 = rstd * g4[i].w;
-                float4 o;
-                o.x = mish_fast(v[i].x * s0 + (be4[i].x - s0 * mean)) + ad4[i].x;
-                o.y = mish_fast(v[i].y * s1 + (be4[i].y - s1 * mean)) + ad4[i].y;
-                o.z = mish_fast(v[i].z * s2 + (be4[i].z - s2 * mean)) + ad4[i].z;
-                o.w = mish_fast(v[i].w * s3 + (be4[i].w - s3 * mean)) + ad4[i].w;
-                *reinterpret_cast<float4*>(p.dst + ((size_t)b * L + l) * p.Cout + ch) = o;
+                *reinterpret_cast<float4*>(p.dst + ((size_t)b * LOUT + l) * p.Cout + ch) = v[i];
             }
         }
     }
@@ -376,17 +407,17 @@ inline void pack_fragments(const float* w_tco_ci, int cout, int cin, int kt0, in
             }
 }
 
-template <int CG, int L, bool RES, int NW>
+template <int KIND, int CG, int LIN, bool RES, int NW>
 static int launch_wide_t(const RcbP& p, hipStream_t s) {
     static bool attr_set = false;
-    constexpr size_t bytes = WideCfg<CG, L, RES, NW>::lds_bytes();
+    constexpr size_t bytes = WideCfg<KIND, CG, LIN, RES, NW>::lds_bytes();
     static_assert(bytes <= 160 * 1024, "wide conv kernel exceeds the 160 KiB LDS of a CU");
     if (!attr_set) {
-        EDMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_conv_kernel<CG, L, RES, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        EDMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_conv_kernel<KIND, CG, LIN, RES, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         attr_set = true;
     }
     dim3 grid(p.Cout / CG, (p.B + 31) / 32);
-    hipLaunchKernelGGL((wide_conv_kernel<CG, L, RES, NW>), grid, dim3(NW * 64), bytes, s, p);
+    hipLaunchKernelGGL((wide_conv_kernel<KIND, CG, LIN, RES, NW>), grid, dim3(NW * 64), bytes, s, p);
     return EDMP_OK;
 }
 

@@ -105,6 +105,22 @@ class Context:
         _capi.check(self.lib.edmp_prof_read(self.h, C.byref(ms), C.byref(n), 1 if reset else 0))
         return ms.value, n.value
 
+    def prof_ops(self):
+        """per program op of the loaded UNet: (kernel instance name, launches, summed event ms, executed FLOPs per
+        trajectory per launch) since the last prof_read(reset=True); call BEFORE that reset."""
+        cap = 256
+        n = C.c_int()
+        ms = (C.c_double * cap)()
+        calls = (C.c_int64 * cap)()
+        fl = (C.c_double * cap)()
+        names = C.create_string_buffer(cap * 64)
+        _capi.check(self.lib.edmp_prof_ops(self.h, cap, C.byref(n), ms, calls, fl, names))
+        out = []
+        for i in range(min(n.value, cap)):
+            nm = names.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode()
+            out.append((nm, int(calls[i]), float(ms[i]), float(fl[i])))
+        return out
+
 
 def get_context(device) -> Context:
     idx = _device_index(device)

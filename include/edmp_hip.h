@@ -170,6 +170,10 @@ int edmp_q_sample_dev(edmp_ctx* ctx, const double* x_dev, const double* eps_dev,
 int edmp_prof_enable(edmp_ctx* ctx, int on);
 /* total ms and launch count of the MFMA conv kernels since the last reset (synchronises) */
 int edmp_prof_read(edmp_ctx* ctx, double* conv_ms, int64_t* conv_launches, int reset);
+/* Per-op view of the same instrumentation (bench.py's per-kernel roofline table; no reference counterpart): for every
+ * op i < min(*n_ops, cap) of the loaded UNet's layer program: summed event time [ms], launches, executed FLOPs per
+ * trajectory per launch, and the kernel instance name (64 bytes each, as rocprofv3 prints it without "edmp::"). */
+int edmp_prof_ops(edmp_ctx* ctx, int cap, int* n_ops, double* ms, int64_t* calls, double* flops_exec, char* names);
 
 #ifdef __cplusplus
 }

@@ -64,7 +64,7 @@ static void run_wide(int B, int C1, int C2, bool with_res_add) {
     auto hx2 = rnd((size_t)B * L * std::max(C2, 1), 3, 1.5f);
     auto hb = rnd(Cout, 4, 0.1f), hg = rnd(Cout, 5, 1.0f), hbe = rnd(Cout, 6, 0.3f), htb = rnd(Cout, 7, 0.5f), hrb = rnd(Cout, 8, 0.1f);
     auto hres = rnd((size_t)B * L * Cout, 9, 1.0f);
-    using Cf = WideCfg<CG, L, RES, NW>;
+    using Cf = WideCfg<WK_K5, CG, L, RES, NW>;
     std::vector<float> hWf((size_t)(Cout / 32) * (Cin / 8) * Cf::NSLAB * 256);
     pack_fragments(hW.data(), Cout, Cin, Cf::KT0, Cf::NTAP, RES, hWf.data());
     float *W = up(hW), *Wf = up(hWf), *x1 = up(hx1), *x2 = up(hx2), *bias = up(hb), *gam = up(hg), *bet = up(hbe), *tb = up(htb), *rb = up(hrb), *res = up(hres);
@@ -97,7 +97,7 @@ static void run_wide(int B, int C1, int C2, bool with_res_add) {
     pn.dst = d_new;
     pn.res_out = RES ? r_new : nullptr;
     auto f_old = [&] { launch_rcb_t<CG, L, RES>(p, 0); };
-    auto f_new = [&] { launch_wide_t<CG, L, RES, NW>(pn, 0); };
+    auto f_new = [&] { launch_wide_t<WK_K5, CG, L, RES, NW>(pn, 0); };
     f_old();
     f_new();
     hipError_t e = hipDeviceSynchronize();
@@ -134,13 +134,75 @@ static void run_wide(int B, int C1, int C2, bool with_res_add) {
     for (float* q : {W, Wf, x1, x2, bias, gam, bet, tb, rb, res, d_old, d_new, r_old, r_new}) hipFree(q);
 }
 
+// down/up-sampling conv of a wide level: generic implicit-GEMM kernel (round 1) vs the position-tile kernel
+template <int KIND, int CG, int LIN>
+static void run_rs(int B) {
+    using Cf = WideCfg<KIND, CG, LIN, false, 4>;
+    const int Cout = CG * 8, Cin = Cout, k = Cf::NTAP, Lout = Cf::LOUT;
+    const bool tr = KIND == WK_UP;
+    const float wscale = 1.0f / std::sqrt((float)Cin * k);
+    auto hW = rnd((size_t)k * Cout * Cin, 11, wscale * 1.7f);  // [tap][Cout][Cin]
+    auto hx = rnd((size_t)B * LIN * Cin, 12, 1.5f);
+    auto hb = rnd(Cout, 13, 0.1f);
+    std::vector<float> hWf((size_t)(Cout / 32) * (Cin / 8) * k * 256);
+    pack_fragments(hW.data(), Cout, Cin, 0, k, false, hWf.data());
+    float *W = up(hW), *Wf = up(hWf), *x = up(hx), *bias = up(hb);
+    const size_t nout = (size_t)B * Lout * Cout;
+    float *d_old, *d_new;
+    hipMalloc((void**)&d_old, nout * 4);
+    hipMalloc((void**)&d_new, nout * 4);
+    hipMemset(d_new, 0xff, nout * 4);
+    ConvP c{};
+    c.src1 = x;
+    c.C1 = Cin;
+    c.Lin = LIN;
+    c.Lout = Lout;
+    c.ntaps = k;
+    c.stride = 2;
+    c.pad = 1;
+    c.transposed = tr;
+    c.W = W;
+    c.bias = bias;
+    c.dst = d_old;
+    c.Cout = Cout;
+    c.B = B;
+    RcbP p{};
+    p.src1 = x;
+    p.C1 = Cin;
+    p.W = Wf;
+    p.bias = bias;
+    p.dst = d_new;
+    p.Cout = Cout;
+    p.B = B;
+    auto f_old = [&] { launch_conv(c, 0); };
+    auto f_new = [&] { launch_wide_t<KIND, CG, LIN, false, 4>(p, 0); };
+    f_old();
+    f_new();
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        printf("rs<%d,%d,%d>: launch failed: %s\n", KIND, CG, LIN, hipGetErrorString(e));
+        return;
+    }
+    double rm = 0;
+    const double d1 = max_abs_diff(d_old, d_new, nout, &rm);
+    float t_old = 1e9f, t_new = 1e9f;
+    for (int round = 0; round < 5; ++round) {
+        t_old = std::min(t_old, time_us(f_old, 50));
+        t_new = std::min(t_new, time_us(f_new, 50));
+    }
+    const double fl = 2.0 * B * (double)Cout * Cin * Cf::valid_pairs();
+    printf("%s<%2d,Lin %d->%d>  C=%4d  max|d| %.2e (ref %.1f) | old %7.2f us %6.1f TF | new %7.2f us %6.1f TF (%.3f of 157.3) | x%.3f\n", tr ? "convT k4s2" : "conv  k3s2",
+           CG, LIN, Lout, Cin, d1, rm, t_old, fl / t_old / 1e6, t_new, fl / t_new / 1e6, fl / t_new / 1e6 / 157.3, t_old / t_new);
+    for (float* q : {W, Wf, x, bias, d_old, d_new}) hipFree(q);
+}
+
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 1024;
     run_wide<64, 2, false, 4>(B, 512, 0, true);
-    run_wide<64, 2, false, 8>(B, 512, 0, true);
-    run_wide<64, 2, true, 8>(B, 512, 512, false);
-    run_wide<64, 4, false, 8>(B, 512, 0, false);
-    run_wide<32, 4, false, 8>(B, 256, 0, true);
+    run_rs<WK_DOWN, 64, 4>(B);
+    run_rs<WK_UP, 64, 2>(B);
+    run_rs<WK_DOWN, 32, 7>(B);
+    run_rs<WK_UP, 32, 4>(B);
     run_wide<64, 2, true, 4>(B, 512, 512, false);
     run_wide<64, 4, false, 4>(B, 512, 0, false);
     run_wide<64, 4, true, 4>(B, 256, 0, false);
