@@ -1260,9 +1260,12 @@ static int launch_gn(const GnP& p, hipStream_t s) {
     return EDMP_OK;
 }
 
+// position-tile kernel (wide.hip) instances: channels per GroupNorm group cg = Cout/8 and the input length select
+// the tile height MS (32 samples for cg >= 32, 16 for the 128-channel levels)
+static int wide_ms(int cout) { return cout / 8 >= 32 ? 32 : 16; }
 static bool rcb_supported(int cout, int L, int c1, int c2) {
     const int cg = cout / 8;
-    const bool shape = (cg == 64 && (L == 2 || L == 4)) || (cg == 32 && (L == 4 || L == 7));
+    const bool shape = (cg == 64 && (L == 2 || L == 4)) || (cg == 32 && (L == 4 || L == 7)) || (cg == 16 && (L == 7 || L == 13));
     return shape && cout % 8 == 0 && c1 % 32 == 0 && c2 % 32 == 0;
 }
 template <int CB, int L, int SB, int KC>
@@ -1345,10 +1348,15 @@ static int launch_blk(const BlkP& p, int variant, hipStream_t s) {
 static int launch_rcb(const RcbP& p, int L, hipStream_t s) {
     const int cg = p.Cout / 8;
     const bool res = p.res_out != nullptr;
-    if (cg == 64 && L == 2) return res ? launch_wide_t<WK_K5, 64, 2, true, 4>(p, s) : launch_wide_t<WK_K5, 64, 2, false, 4>(p, s);
-    if (cg == 64 && L == 4) return res ? launch_wide_t<WK_K5, 64, 4, true, 4>(p, s) : launch_wide_t<WK_K5, 64, 4, false, 4>(p, s);
-    if (cg == 32 && L == 4) return res ? launch_wide_t<WK_K5, 32, 4, true, 4>(p, s) : launch_wide_t<WK_K5, 32, 4, false, 4>(p, s);
-    if (cg == 32 && L == 7) return res ? launch_wide_t<WK_K5, 32, 7, true, 4>(p, s) : launch_wide_t<WK_K5, 32, 7, false, 4>(p, s);
+#define EDMP_K5(MS, CG, GS, LL) \
+    return res ? launch_wide_t<WK_K5, MS, CG, GS, LL, true>(p, s) : launch_wide_t<WK_K5, MS, CG, GS, LL, false>(p, s);
+    if (cg == 64 && L == 2) { EDMP_K5(32, 64, 64, 2) }
+    if (cg == 64 && L == 4) { EDMP_K5(32, 64, 64, 4) }
+    if (cg == 32 && L == 4) { EDMP_K5(32, 32, 32, 4) }
+    if (cg == 32 && L == 7) { EDMP_K5(32, 32, 32, 7) }
+    if (cg == 16 && L == 7) { EDMP_K5(16, 32, 16, 7) }
+    if (cg == 16 && L == 13) { EDMP_K5(16, 32, 16, 13) }
+#undef EDMP_K5
     set_error("no fused conv+GroupNorm kernel for Cout=%d L=%d", p.Cout, L);
     return EDMP_ERR_STATE;
 }
@@ -1356,23 +1364,22 @@ static int launch_rcb(const RcbP& p, int L, hipStream_t s) {
 // down/up-sampling convs of the wide levels (no GroupNorm behind them) on the position-tile kernel
 static bool wrs_supported(int cout, int cin, int Lin, bool transposed) {
     const int cg = cout / 8;
-    if (cout % 8 != 0 || cin % 32 != 0 || !(cg == 32 || cg == 64)) return false;
-    return transposed ? (Lin == 2 || Lin == 4) : (Lin == 4 || Lin == 7);
+    if (cout % 8 != 0 || cin % 32 != 0) return false;
+    if (transposed) return (cg == 64 && Lin == 2) || (cg == 32 && Lin == 4) || (cg == 16 && Lin == 7);
+    return (cg == 64 && Lin == 4) || (cg == 32 && Lin == 7) || (cg == 16 && Lin == 13);
 }
 static int launch_wrs(const RcbP& p, int kind, int Lin, hipStream_t s) {
     const int cg = p.Cout / 8;
     if (kind == WK_DOWN) {
-        if (cg == 64 && Lin == 4) return launch_wide_t<WK_DOWN, 64, 4, false, 4>(p, s);
-        if (cg == 32 && Lin == 4) return launch_wide_t<WK_DOWN, 32, 4, false, 4>(p, s);
-        if (cg == 64 && Lin == 7) return launch_wide_t<WK_DOWN, 64, 7, false, 4>(p, s);
-        if (cg == 32 && Lin == 7) return launch_wide_t<WK_DOWN, 32, 7, false, 4>(p, s);
+        if (cg == 64 && Lin == 4) return launch_wide_t<WK_DOWN, 32, 64, 64, 4, false>(p, s);
+        if (cg == 32 && Lin == 7) return launch_wide_t<WK_DOWN, 32, 32, 32, 7, false>(p, s);
+        if (cg == 16 && Lin == 13) return launch_wide_t<WK_DOWN, 16, 32, 16, 13, false>(p, s);
     } else {
-        if (cg == 64 && Lin == 2) return launch_wide_t<WK_UP, 64, 2, false, 4>(p, s);
-        if (cg == 32 && Lin == 2) return launch_wide_t<WK_UP, 32, 2, false, 4>(p, s);
-        if (cg == 64 && Lin == 4) return launch_wide_t<WK_UP, 64, 4, false, 4>(p, s);
-        if (cg == 32 && Lin == 4) return launch_wide_t<WK_UP, 32, 4, false, 4>(p, s);
+        if (cg == 64 && Lin == 2) return launch_wide_t<WK_UP, 32, 64, 64, 2, false>(p, s);
+        if (cg == 32 && Lin == 4) return launch_wide_t<WK_UP, 32, 32, 32, 4, false>(p, s);
+        if (cg == 16 && Lin == 7) return launch_wide_t<WK_UP, 16, 32, 16, 7, false>(p, s);
     }
-    set_error("no wide resampling kernel for kind=%d Cout=%d Lin=%d", kind, p.Cout, Lin);
+    set_error("no position-tile resampling kernel for kind=%d Cout=%d Lin=%d", kind, p.Cout, Lin);
     return EDMP_ERR_STATE;
 }
 
@@ -1385,8 +1392,11 @@ static void op_kernel_name(const Op& op, char* out) {
                                       "rcb_block_kernel<64, 25, 4, 16, true>", "rcb_block_kernel<64, 25, 4, 16, false>", "rcb_block_kernel<64, 13, 4, 32, true>",
                                       "rcb_block_kernel<64, 13, 4, 32, false>", "rcb_block_kernel<32, 25, 4, 32, true>", "rcb_block_kernel<32, 25, 4, 32, false>"};
     if (op.kind == OP_RCB && op.rc_rows) snprintf(out, 64, "%s", rows_names[op.rc_rows]);
-    else if (op.kind == OP_RCB) snprintf(out, 64, "wide_conv_kernel<0, %d, %d, %s, 4>", op.rc.Cout / 8, op.rc_L, op.rc.res_out ? "true" : "false");
-    else if (op.kind == OP_WRS) snprintf(out, 64, "wide_conv_kernel<%d, %d, %d, false, 4>", op.wrs_kind, op.rc.Cout / 8, op.rc_L);
+    else if (op.kind == OP_RCB || op.kind == OP_WRS) {
+        const int cg = op.rc.Cout / 8, ms = wide_ms(op.rc.Cout);
+        snprintf(out, 64, "wide_conv_kernel<%d, %d, %d, %d, %d, %s>", op.kind == OP_RCB ? 0 : op.wrs_kind, ms, cg < 32 ? 32 : cg, cg, op.rc_L,
+                 (op.kind == OP_RCB && op.rc.res_out) ? "true" : "false");
+    }
     else if (op.kind == OP_BLK) snprintf(out, 64, "%s", blk_names[op.bk_variant]);
     else if (op.kind == OP_CONV) {
         const int kc = pick_kc(op.cv);
@@ -1434,6 +1444,7 @@ struct Packer {
     // Conv1d k5 weight (Cout, Cin, 5) [+ the block's residual 1x1 conv (Cout, Cin, 1)] -> the B-fragment stream of
     // wide_conv_kernel: [Cout/32][CinP/8][slots][64][4], slots = the taps that can be valid at length L (+ the residual)
     size_t conv_frag(const float* w, const float* wres, int cout, int cin, int cinp, int L) {
+        const int sw = wide_ms(cout);
         const int kt0 = (L == 2) ? 1 : 0, ntap = (L == 2) ? 3 : 5, nslab = ntap + (wres ? 1 : 0);
         std::vector<float> tmp((size_t)6 * cout * cinp, 0.0f);
         for (int co = 0; co < cout; ++co)
@@ -1441,8 +1452,8 @@ struct Packer {
                 for (int t = 0; t < 5; ++t) tmp[((size_t)t * cout + co) * cinp + ci] = w[((size_t)co * cin + ci) * 5 + t];
                 if (wres) tmp[((size_t)5 * cout + co) * cinp + ci] = wres[(size_t)co * cin + ci];
             }
-        size_t o = add((size_t)(cout / 32) * (cinp / 8) * nslab * 256);
-        pack_fragments(tmp.data(), cout, cinp, kt0, ntap, wres != nullptr, &host[o]);
+        size_t o = add((size_t)(cout / sw) * (cinp / (sw == 32 ? 8 : 16)) * nslab * 256);
+        pack_fragments(tmp.data(), cout, cinp, kt0, ntap, wres != nullptr, &host[o], sw);
         return o;
     }
     // strided Conv1d k3 (Cout, Cin, 3) or ConvTranspose1d k4 (Cin, Cout, 4) of a wide level -> fragment stream, slot = tap
@@ -1452,8 +1463,9 @@ struct Packer {
             for (int ci = 0; ci < cin; ++ci)
                 for (int t = 0; t < k; ++t)
                     tmp[((size_t)t * cout + co) * cin + ci] = transposed ? w[((size_t)ci * cout + co) * k + t] : w[((size_t)co * cin + ci) * k + t];
-        size_t o = add((size_t)(cout / 32) * (cin / 8) * k * 256);
-        pack_fragments(tmp.data(), cout, cin, 0, k, false, &host[o]);
+        const int sw = wide_ms(cout);
+        size_t o = add((size_t)(cout / sw) * (cin / (sw == 32 ? 8 : 16)) * k * 256);
+        pack_fragments(tmp.data(), cout, cin, 0, k, false, &host[o], sw);
         return o;
     }
     size_t vec(const float* v, int n) {

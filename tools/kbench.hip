@@ -54,19 +54,22 @@ static float time_us(F&& f, int iters) {
     return ms * 1000.f / iters;
 }
 
-template <int CG, int L, bool RES, int NW>
+// Conv1dBlock (k5 + GroupNorm + Mish + add [+ folded residual 1x1 conv]): round-1 kernel(s) vs the position-tile kernel.
+// MS = 32: reference = legacy rcb_conv_kernel; MS = 16 (128-channel levels): reference = rcb_rows_kernel (+ conv_mfma for the
+// residual 1x1 conv, which round 1 ran as its own launch)
+template <int MS, int CG, int GS, int L, bool RES>
 static void run_wide(int B, int C1, int C2, bool with_res_add) {
-    const int Cout = CG * 8, Cin = C1 + C2;
-    const int ntap_store = RES ? 6 : 5;
+    const int Cout = GS * 8, Cin = C1 + C2;
+    const int ntap_store = 6;
     const float wscale = 1.0f / std::sqrt((float)Cin * 5);
     auto hW = rnd((size_t)ntap_store * Cout * Cin, 1, wscale * 1.7f);
     auto hx1 = rnd((size_t)B * L * C1, 2, 1.5f);
     auto hx2 = rnd((size_t)B * L * std::max(C2, 1), 3, 1.5f);
     auto hb = rnd(Cout, 4, 0.1f), hg = rnd(Cout, 5, 1.0f), hbe = rnd(Cout, 6, 0.3f), htb = rnd(Cout, 7, 0.5f), hrb = rnd(Cout, 8, 0.1f);
     auto hres = rnd((size_t)B * L * Cout, 9, 1.0f);
-    using Cf = WideCfg<WK_K5, CG, L, RES, NW>;
-    std::vector<float> hWf((size_t)(Cout / 32) * (Cin / 8) * Cf::NSLAB * 256);
-    pack_fragments(hW.data(), Cout, Cin, Cf::KT0, Cf::NTAP, RES, hWf.data());
+    using Cf = WideCfg<WK_K5, MS, CG, GS, L, RES>;
+    std::vector<float> hWf((size_t)(Cout / Cf::SW) * (Cin / Cf::KG) * Cf::NSLAB * 256);
+    pack_fragments(hW.data(), Cout, Cin, Cf::KT0, Cf::NTAP, RES, hWf.data(), Cf::SW);
     float *W = up(hW), *Wf = up(hWf), *x1 = up(hx1), *x2 = up(hx2), *bias = up(hb), *gam = up(hg), *bet = up(hbe), *tb = up(htb), *rb = up(hrb), *res = up(hres);
     float *d_old, *d_new, *r_old, *r_new;
     const size_t nout = (size_t)B * L * Cout;
@@ -90,19 +93,41 @@ static void run_wide(int B, int C1, int C2, bool with_res_add) {
     p.dst = d_old;
     p.Cout = Cout;
     p.B = B;
-    p.res_out = RES ? r_old : nullptr;
+    p.res_out = (RES && MS == 32) ? r_old : nullptr;
     p.res_bias = RES ? rb : nullptr;
     RcbP pn = p;
     pn.W = Wf;
     pn.dst = d_new;
     pn.res_out = RES ? r_new : nullptr;
-    auto f_old = [&] { launch_rcb_t<CG, L, RES>(p, 0); };
-    auto f_new = [&] { launch_wide_t<WK_K5, CG, L, RES, NW>(pn, 0); };
+    ConvP c{};  // the residual 1x1 conv as round 1 ran it on the 128-channel levels
+    c.src1 = x1;
+    c.src2 = C2 ? x2 : nullptr;
+    c.C1 = C1;
+    c.C2 = C2;
+    c.Lin = L;
+    c.Lout = L;
+    c.ntaps = 1;
+    c.stride = 1;
+    c.pad = 0;
+    c.transposed = 0;
+    c.W = W + (size_t)5 * Cout * Cin;
+    c.bias = rb;
+    c.dst = r_old;
+    c.Cout = Cout;
+    c.B = B;
+    auto f_old = [&] {
+        if constexpr (MS == 32) launch_rcb_t<CG, L, RES>(p, 0);
+        else {
+            launch_rows(p, rows_variant(Cout, L, C1, C2), 0);
+            if (RES) launch_conv(c, 0);
+        }
+    };
+    auto f_new = [&] { launch_wide_t<WK_K5, MS, CG, GS, L, RES>(pn, 0); };
     f_old();
     f_new();
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) {
-        printf("<%d,%d,%d,NW%d> C1=%d C2=%d: launch failed: %s\n", CG, L, (int)RES, NW, C1, C2, hipGetErrorString(e));
+        printf("<%d,%d,%d,%d> C1=%d C2=%d: launch failed: %s\n", MS, GS, L, (int)RES, C1, C2, hipGetErrorString(e));
         return;
     }
     double rm = 0, rm2 = 0;
@@ -113,21 +138,16 @@ static void run_wide(int B, int C1, int C2, bool with_res_add) {
         t_old = std::min(t_old, time_us(f_old, 50));
         t_new = std::min(t_new, time_us(f_new, 50));
     }
-    // executed FLOPs: valid (out, in) position pairs
-    long pairs = 0;
-    for (int l = 0; l < L; ++l)
-        for (int lp = 0; lp < L; ++lp)
-            if (std::abs(l - lp) <= 2) ++pairs;
-    const double fl = 2.0 * B * (double)Cout * Cin * (pairs + (RES ? L : 0));
-    printf("<%2d,%d,%d,NW%d> Cin=%4d+%4d  max|d| %.2e (ref %.1f) res %.2e | old %7.2f us %6.1f TF | new %7.2f us %6.1f TF (%.3f of 157.3) | x%.3f\n", CG, L,
-           (int)RES, NW, C1, C2, d1, rm, d2, t_old, fl / t_old / 1e6, t_new, fl / t_new / 1e6, fl / t_new / 1e6 / 157.3, t_old / t_new);
+    const double fl = 2.0 * B * (double)Cout * Cin * (Cf::valid_pairs() + (RES ? L : 0));
+    printf("k5<MS%d,cg%2d,L%2d,res%d> Cin=%4d+%4d  max|d| %.2e (ref %.1f) res %.2e | old %7.2f us %6.1f TF | new %7.2f us %6.1f TF (%.3f of 157.3) | x%.3f\n", MS, GS, L,
+           (int)RES, C1, C2, d1, rm, d2, t_old, fl / t_old / 1e6, t_new, fl / t_new / 1e6, fl / t_new / 1e6 / 157.3, t_old / t_new);
 #ifdef EDMP_STAMPS
     {
-        f_new();
+        for (int i = 0; i < 20; ++i) f_new();
         hipDeviceSynchronize();
         unsigned long long st[8][16];
         hipMemcpyFromSymbol(st, HIP_SYMBOL(edmp::g_stamps), sizeof(st));
-        printf("      stamps (shader cycles | 100MHz ticks): prologue %llu | K loop %llu | spill %llu | stats+store %llu | total %llu cyc = %.2f us\n", st[0][2] - st[0][0],
+        printf("      stamps (shader cycles): prologue %llu | K loop %llu | spill %llu | stats+store %llu | total %llu cyc = %.2f us\n", st[0][2] - st[0][0],
                st[0][4] - st[0][2], st[0][6] - st[0][4], st[0][8] - st[0][6], st[0][8] - st[0][0], (st[0][9] - st[0][1]) / 100.0);
     }
 #endif
@@ -135,17 +155,17 @@ static void run_wide(int B, int C1, int C2, bool with_res_add) {
 }
 
 // down/up-sampling conv of a wide level: generic implicit-GEMM kernel (round 1) vs the position-tile kernel
-template <int KIND, int CG, int LIN>
+template <int KIND, int MS, int CG, int GS, int LIN>
 static void run_rs(int B) {
-    using Cf = WideCfg<KIND, CG, LIN, false, 4>;
-    const int Cout = CG * 8, Cin = Cout, k = Cf::NTAP, Lout = Cf::LOUT;
+    using Cf = WideCfg<KIND, MS, CG, GS, LIN, false>;
+    const int Cout = GS * 8, Cin = Cout, k = Cf::NTAP, Lout = Cf::LOUT;
     const bool tr = KIND == WK_UP;
     const float wscale = 1.0f / std::sqrt((float)Cin * k);
     auto hW = rnd((size_t)k * Cout * Cin, 11, wscale * 1.7f);  // [tap][Cout][Cin]
     auto hx = rnd((size_t)B * LIN * Cin, 12, 1.5f);
     auto hb = rnd(Cout, 13, 0.1f);
-    std::vector<float> hWf((size_t)(Cout / 32) * (Cin / 8) * k * 256);
-    pack_fragments(hW.data(), Cout, Cin, 0, k, false, hWf.data());
+    std::vector<float> hWf((size_t)(Cout / Cf::SW) * (Cin / Cf::KG) * k * 256);
+    pack_fragments(hW.data(), Cout, Cin, 0, k, false, hWf.data(), Cf::SW);
     float *W = up(hW), *Wf = up(hWf), *x = up(hx), *bias = up(hb);
     const size_t nout = (size_t)B * Lout * Cout;
     float *d_old, *d_new;
@@ -175,12 +195,12 @@ static void run_rs(int B) {
     p.Cout = Cout;
     p.B = B;
     auto f_old = [&] { launch_conv(c, 0); };
-    auto f_new = [&] { launch_wide_t<KIND, CG, LIN, false, 4>(p, 0); };
+    auto f_new = [&] { launch_wide_t<KIND, MS, CG, GS, LIN, false>(p, 0); };
     f_old();
     f_new();
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) {
-        printf("rs<%d,%d,%d>: launch failed: %s\n", KIND, CG, LIN, hipGetErrorString(e));
+        printf("rs<%d,%d,%d>: launch failed: %s\n", KIND, GS, LIN, hipGetErrorString(e));
         return;
     }
     double rm = 0;
@@ -198,17 +218,25 @@ static void run_rs(int B) {
 
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 1024;
-    run_wide<64, 2, false, 4>(B, 512, 0, true);
-    run_rs<WK_DOWN, 64, 4>(B);
-    run_rs<WK_UP, 64, 2>(B);
-    run_rs<WK_DOWN, 32, 7>(B);
-    run_rs<WK_UP, 32, 4>(B);
-    run_wide<64, 2, true, 4>(B, 512, 512, false);
-    run_wide<64, 4, false, 4>(B, 512, 0, false);
-    run_wide<64, 4, true, 4>(B, 256, 0, false);
-    run_wide<32, 4, false, 4>(B, 256, 0, true);
-    run_wide<32, 4, true, 4>(B, 512, 512, false);
-    run_wide<32, 7, false, 4>(B, 256, 0, true);
-    run_wide<32, 7, true, 4>(B, 128, 0, false);
+    // 128-channel levels (16-sample tiles, 16x16x4 MFMA)
+    run_wide<16, 32, 16, 13, false>(B, 128, 0, true);
+    run_wide<16, 32, 16, 13, true>(B, 64, 0, false);
+    run_wide<16, 32, 16, 7, false>(B, 128, 0, true);
+    run_wide<16, 32, 16, 7, true>(B, 256, 256, false);
+    run_rs<WK_DOWN, 16, 32, 16, 13>(B);
+    run_rs<WK_UP, 16, 32, 16, 7>(B);
+    // >= 256 channels (32-sample tiles, 32x32x2 MFMA)
+    run_wide<32, 64, 64, 2, false>(B, 512, 0, true);
+    run_wide<32, 64, 64, 2, true>(B, 512, 512, false);
+    run_wide<32, 64, 64, 4, false>(B, 512, 0, false);
+    run_wide<32, 64, 64, 4, true>(B, 256, 0, false);
+    run_wide<32, 32, 32, 4, false>(B, 256, 0, true);
+    run_wide<32, 32, 32, 4, true>(B, 512, 512, false);
+    run_wide<32, 32, 32, 7, false>(B, 256, 0, true);
+    run_wide<32, 32, 32, 7, true>(B, 128, 0, false);
+    run_rs<WK_DOWN, 32, 64, 64, 4>(B);
+    run_rs<WK_UP, 32, 64, 64, 2>(B);
+    run_rs<WK_DOWN, 32, 32, 32, 7>(B);
+    run_rs<WK_UP, 32, 32, 32, 4>(B);
     return 0;
 }
