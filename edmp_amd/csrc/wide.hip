@@ -102,6 +102,7 @@ struct WideCfg {
         return a > y ? a : y;
     }
     static_assert(MS == 32 || MS == 16, "tile height 32 (32x32x2 MFMA) or 16 (16x16x4 MFMA)");
+    static_assert(NBLK >= 3 && 4 * (NBLK - 1) >= 1, "the memory work of a step is spread over the blocks before the last");
     static_assert(CG % SW == 0 && NW % S == 0 && S <= NW, "slabs per workgroup must divide the wave count");
     static_assert(!RES || KIND == WK_K5, "the folded residual 1x1 conv belongs to a Conv1dBlock");
     static_assert((LOUT * CG) % 4 == 0, "whole float4 columns");
@@ -225,17 +226,21 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
         const float* src = first ? p.src1 : p.src2;
         const int ci0 = (first ? nca : nca - ch1) * KC;
         const float* w = wb + ((size_t)(ncb * (KC / KG) + ks * QW)) * (NSLAB * 256);
-        // side work of MFMA block X of the step's NBLK: items [X*NSIDE/NBLK, (X+1)*NSIDE/NBLK) of the list
-        // (NA activation loads, NBL weight loads, NA commits): loads first, the commits as late as possible
+        // side work: the step's memory items (NA activation loads, NBL weight loads, NA commits of the staged chunk, in
+        // that order) are spread over SLOTS: one slot after each of the four component rounds of every MFMA block
+        // except the last block (whose shadow is too short for a ds_write to complete before the step's barrier)
         auto side = [&](auto xc) __attribute__((always_inline)) {
-            constexpr int X = decltype(xc)::value;
-            static_for<X * NSIDE / NBLK, (X + 1) * NSIDE / NBLK>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int X = decltype(xc)::value;  // slot index
+            constexpr int NSLOT = 4 * (NBLK - 1);
+            static_for<0, NSIDE>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
-                if constexpr (j < NA) ra[j] = *reinterpret_cast<const f32x4*>(src + (first ? a_g1[j] : a_g2[j]) + ci0);
-                else if constexpr (j < NA + NBL) bn[(j - NA) / NSLAB][(j - NA) % NSLAB] = *reinterpret_cast<const float4*>(w + (j - NA) * 256);
-                else {
-                    constexpr int k = j - NA - NBL;
-                    if ((A_F4 % NTH == 0) || tid + k * NTH < A_F4) *reinterpret_cast<f32x4*>(stw + a_l[k]) = ra[k];
+                if constexpr (j * NSLOT / NSIDE == X) {
+                    if constexpr (j < NA) ra[j] = *reinterpret_cast<const f32x4*>(src + (first ? a_g1[j] : a_g2[j]) + ci0);
+                    else if constexpr (j < NA + NBL) bn[(j - NA) / NSLAB][(j - NA) % NSLAB] = *reinterpret_cast<const float4*>(w + (j - NA) * 256);
+                    else {
+                        constexpr int k = j - NA - NBL;
+                        if ((A_F4 % NTH == 0) || tid + k * NTH < A_F4) *reinterpret_cast<f32x4*>(stw + a_l[k]) = ra[k];
+                    }
                 }
             });
         };
@@ -243,27 +248,31 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
             constexpr int q = decltype(qc)::value;
             static_for<0, L>([&](auto lpc) __attribute__((always_inline)) {
                 constexpr int lp = decltype(lpc)::value;
+                constexpr int X = q * L + lp;  // block index
                 // next A fragment: (lp+1, q) | (0, q+1) | first fragment of the next chunk
                 const float* an_p = (lp + 1 < L) ? st + frag + (lp + 1) * (MS * LDK) + KG * q
                                     : (q + 1 < QW) ? st + frag + KG * (q + 1)
                                                    : stn + frag;
                 const float4 an = *reinterpret_cast<const float4*>(an_p);
-                side(std::integral_constant<int, q * L + lp>{});
-                __builtin_amdgcn_sched_barrier(0);  // memory work strictly BETWEEN the MFMA blocks
                 // the block: component-major over the tiles this A fragment feeds, so that consecutive MFMAs go to
-                // different accumulators (the 16x16x4 MFMA has 40 cycles of dependent latency for 32 of issue)
-#define EDMP_W_COMP(J)                                                                                                      \
+                // different accumulators (the 16x16x4 MFMA has 40 cycles of dependent latency for 32 of issue); after
+                // each round one slot of memory work rides in the shadow of the round's last MFMA
+#define EDMP_W_COMP(J, R)                                                                                                   \
     static_for<0, LOUT>([&](auto lc) __attribute__((always_inline)) {                                                     \
         constexpr int l = decltype(lc)::value;                                                                              \
         if constexpr (Cf::slot(l, lp) >= 0) { EDMP_W_MFMA(acc[l], bc[q][Cf::slot(l, lp) >= 0 ? Cf::slot(l, lp) : 0], J) }   \
     });                                                                                                                     \
-    if constexpr (RES) { EDMP_W_MFMA(racc[lp], bc[q][NTAP], J) }
-                EDMP_W_COMP(x)
-                EDMP_W_COMP(y)
-                EDMP_W_COMP(z)
-                EDMP_W_COMP(w)
+    if constexpr (RES) { EDMP_W_MFMA(racc[lp], bc[q][NTAP], J) }                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    if constexpr (X < NBLK - 1) {                                                                                           \
+        side(std::integral_constant<int, 4 * X + R>{});                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    }
+                EDMP_W_COMP(x, 0)
+                EDMP_W_COMP(y, 1)
+                EDMP_W_COMP(z, 2)
+                EDMP_W_COMP(w, 3)
 #undef EDMP_W_COMP
-                __builtin_amdgcn_sched_barrier(0);
                 a4 = an;
             });
         });

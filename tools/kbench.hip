@@ -216,8 +216,111 @@ static void run_rs(int B) {
     for (float* q : {W, Wf, x, bias, d_old, d_new}) hipFree(q);
 }
 
+__global__ void spin_kernel(long long cycles) {
+    const long long t0 = clock64();
+    while (clock64() - t0 < cycles) {}
+}
+
+// Experiment: does running two half-batch chains on two streams (16-sample workgroups, 256 per launch, two co-resident
+// per CU from DIFFERENT launches) hide the per-launch fixed costs?  One chain of NCH launches of the 32-sample kernel at
+// B rows vs two chains of NCH launches of the 16-sample kernel at B/2 rows each, the second stream offset by one launch.
+template <int CG, int GS, int L>
+static void run_dual(int B, int C1, int nch) {
+    const int Cout = GS * 8, Cin = C1;
+    const float wscale = 1.0f / std::sqrt((float)Cin * 5);
+    auto hW = rnd((size_t)6 * Cout * Cin, 1, wscale * 1.7f);
+    auto hx1 = rnd((size_t)B * L * C1, 2, 1.5f);
+    auto hb = rnd(Cout, 4, 0.1f), hg = rnd(Cout, 5, 1.0f), hbe = rnd(Cout, 6, 0.3f), htb = rnd(Cout, 7, 0.5f);
+    using C32 = WideCfg<WK_K5, 32, CG, GS, L, false>;
+    using C16 = WideCfg<WK_K5, 16, CG, GS, L, false>;
+    std::vector<float> hWf32((size_t)(Cout / 32) * (Cin / 8) * C32::NSLAB * 256), hWf16((size_t)(Cout / 16) * (Cin / 16) * C16::NSLAB * 256);
+    pack_fragments(hW.data(), Cout, Cin, C32::KT0, C32::NTAP, false, hWf32.data(), 32);
+    pack_fragments(hW.data(), Cout, Cin, C16::KT0, C16::NTAP, false, hWf16.data(), 16);
+    float *Wf32 = up(hWf32), *Wf16 = up(hWf16), *x1 = up(hx1), *bias = up(hb), *gam = up(hg), *bet = up(hbe), *tb = up(htb);
+    const size_t nout = (size_t)B * L * Cout;
+    float *d32, *d16;
+    hipMalloc((void**)&d32, nout * 4);
+    hipMalloc((void**)&d16, nout * 4);
+    RcbP p{};
+    p.src1 = x1;
+    p.C1 = C1;
+    p.W = Wf32;
+    p.bias = bias;
+    p.gamma = gam;
+    p.beta = bet;
+    p.add_tb = tb;
+    p.dst = d32;
+    p.Cout = Cout;
+    p.B = B;
+    RcbP pa = p, pb = p;
+    pa.W = pb.W = Wf16;
+    pa.B = pb.B = B / 2;
+    pa.dst = d16;
+    pb.src1 = x1 + (size_t)(B / 2) * L * C1;
+    pb.dst = d16 + (size_t)(B / 2) * L * Cout;
+    hipStream_t sa, sb;
+    hipStreamCreate(&sa);
+    hipStreamCreate(&sb);
+    hipEvent_t e0, e1, ea, eb;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventCreateWithFlags(&ea, hipEventDisableTiming);
+    hipEventCreateWithFlags(&eb, hipEventDisableTiming);
+    auto single = [&] {
+        for (int i = 0; i < nch; ++i) launch_wide_t<WK_K5, 32, CG, GS, L, false>(p, sa);
+    };
+    auto single16 = [&] {  // the 16-sample kernel on the whole batch (512 workgroups per launch, one stream)
+        RcbP q = pa;
+        q.B = B;
+        for (int i = 0; i < nch; ++i) launch_wide_t<WK_K5, 16, CG, GS, L, false>(q, sa);
+    };
+    auto dual = [&](int offset_us) {
+        hipEventRecord(ea, sa);
+        hipStreamWaitEvent(sb, ea, 0);  // fork
+        if (offset_us) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, sb, (long long)offset_us * 2100);  // stream b starts late
+        for (int i = 0; i < nch; ++i) launch_wide_t<WK_K5, 16, CG, GS, L, false>(pa, sa);
+        for (int i = 0; i < nch; ++i) launch_wide_t<WK_K5, 16, CG, GS, L, false>(pb, sb);
+        hipEventRecord(eb, sb);
+        hipStreamWaitEvent(sa, eb, 0);  // join
+    };
+    auto timeit = [&](auto&& f) {
+        float best = 1e9f;
+        for (int r = 0; r < 5; ++r) {
+            hipEventRecord(e0, sa);
+            f();
+            hipEventRecord(e1, sa);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            best = std::min(best, ms * 1000.f);
+        }
+        return best;
+    };
+    single();
+    dual(5);
+    hipDeviceSynchronize();
+    double rm = 0;
+    const double d = max_abs_diff(d32, d16, nout, &rm);
+    const float t1 = timeit(single), t16 = timeit(single16), t2 = timeit([&] { dual(0); });
+    printf("dual<cg%d,L%d> Cin=%d x%d launches: max|d| %.2e | 1 stream MS32 %.1f us (%.2f/launch) | 1 stream MS16 %.1f | 2 streams MS16 aligned %.1f |", GS, L, C1, nch, d, t1, t1 / nch, t16, t2);
+    for (int off : {3, 6, 9, 12, 18, 25}) {
+        const float t3 = timeit([&] { dual(off); });
+        printf(" +%dus: %.1f (x%.3f)", off, t3, t1 / t3);
+    }
+    printf("\n");
+    for (float* q : {Wf32, Wf16, x1, bias, gam, bet, tb, d32, d16}) hipFree(q);
+    hipStreamDestroy(sa);
+    hipStreamDestroy(sb);
+}
+
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 1024;
+    if (argc > 2) {
+        run_dual<64, 64, 2>(B, 512, 20);
+        run_dual<64, 64, 4>(B, 512, 12);
+        run_dual<32, 32, 7>(B, 256, 12);
+        return 0;
+    }
     // 128-channel levels (16-sample tiles, 16x16x4 MFMA)
     run_wide<16, 32, 16, 13, false>(B, 128, 0, true);
     run_wide<16, 32, 16, 13, true>(B, 64, 0, false);
