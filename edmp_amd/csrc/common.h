@@ -103,6 +103,18 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// x + (x of lane ^ M) for M in {1, 2, 4, 8} on the DPP data path (a few cycles) instead of __shfl_xor's ds_bpermute
+// (an LDS round trip, ~100 cycles each; six of them sat on the critical path of every GroupNorm epilogue).
+// M = 1, 2: quad permutes; M = 8: rotate the 16-lane row by 8; M = 4: mirror the 8-lane half-row, which equals
+// lane ^ 4 only for values already uniform within quads - i.e. apply the steps in the order 1, 2, 4, (8).
+template <int M>
+__device__ __forceinline__ float dpp_xor_add(float x) {
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8, "lane-xor distance within a 16-lane row");
+    constexpr int ctrl = (M == 1) ? 0xB1 : (M == 2) ? 0x4E : (M == 4) ? 0x141 : 0x128;
+    const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xF, 0xF, true);
+    return x + __builtin_bit_cast(float, y);
+}
+
 // x * tanh(softplus(x)) with torch's softplus threshold (20): blocks.py:27,65 -> torch.nn.Mish
 __device__ __forceinline__ float mish_f(float x) {
     float sp = (x > 20.0f) ? x : log1pf(expf(x));

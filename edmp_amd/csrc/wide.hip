@@ -196,15 +196,11 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
             for (int t = 0; t < NSLAB; ++t) b[q][t] = *reinterpret_cast<const float4*>(w + (q * NSLAB + t) * 256);
     };
 
-    // ---- prologue: weights of chunk 0 in flight, activation chunks 0 and 1 staged
+    // ---- prologue: weights of chunk 0 in flight, activation chunk 0 staged (chunk 1 is fetched and committed by the first
+    //      K step, next to chunk 2: waiting for two chunks here cost 1-2.5 us of every launch at L >= 4)
     load_b(0, bA);
-    {
-        f32x4 r1[NA];
-        load_a(0, ra);
-        load_a(min(1, nK - 1), r1);
-        commit_a(lds, ra);
-        commit_a(lds + A_FL, r1);
-    }
+    load_a(0, ra);
+    commit_a(lds, ra);
     __syncthreads();
     EDMP_STAMP(0, 1)
 
@@ -220,25 +216,37 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
     // one K step: MFMAs of chunk i on stage `st` with fragments bc; fetch activation chunk i+2 and the weight fragments
     // of chunk i+1 (into bn); commit the fetched activations into stage `stw`; the first A fragment of chunk i+1 is read
     // from `stn` before the barrier.
-    auto step = [&](int i, const float* st, const float* stn, float* stw, float4(&bc)[QW][NSLAB], float4(&bn)[QW][NSLAB]) __attribute__((always_inline)) {
+    f32x4 r1[NA];  // the first step's extra staging set (activation chunk 1)
+    auto step = [&](auto first_c, int i, const float* st, float* stn, float* stw, float4(&bc)[QW][NSLAB], float4(&bn)[QW][NSLAB]) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_c)::value;  // step 0: also fetches chunk 1 and commits it into `stn`
         const int nca = min(i + 2, nK - 1), ncb = min(i + 1, nK - 1);
         const bool first = nca < ch1;
         const float* src = first ? p.src1 : p.src2;
         const int ci0 = (first ? nca : nca - ch1) * KC;
         const float* w = wb + ((size_t)(ncb * (KC / KG) + ks * QW)) * (NSLAB * 256);
         // side work: the step's memory items (NA activation loads, NBL weight loads, NA commits of the staged chunk, in
-        // that order) are spread over SLOTS: one slot after each of the four component rounds of every MFMA block
-        // except the last block (whose shadow is too short for a ds_write to complete before the step's barrier)
+        // that order; the first step also carries chunk 1's loads and commits) are spread over SLOTS: one slot after
+        // each of the four component rounds of every MFMA block except the last block (whose shadow is too short for a
+        // ds_write to complete before the step's barrier)
+        const bool first1 = 1 < ch1 || nK == 1;  // source of chunk 1 (FIRST)
+        const float* src1c = first1 ? p.src1 : p.src2;
+        const int ci1 = (nK == 1) ? 0 : (first1 ? KC : (1 - ch1) * KC);
         auto side = [&](auto xc) __attribute__((always_inline)) {
             constexpr int X = decltype(xc)::value;  // slot index
             constexpr int NSLOT = 4 * (NBLK - 1);
-            static_for<0, NSIDE>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int NX = FIRST ? NA : 0;       // extra loads / commits of the first step
+            constexpr int NITEM = NSIDE + 2 * NX;
+            static_for<0, NITEM>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
-                if constexpr (j * NSLOT / NSIDE == X) {
-                    if constexpr (j < NA) ra[j] = *reinterpret_cast<const f32x4*>(src + (first ? a_g1[j] : a_g2[j]) + ci0);
-                    else if constexpr (j < NA + NBL) bn[(j - NA) / NSLAB][(j - NA) % NSLAB] = *reinterpret_cast<const float4*>(w + (j - NA) * 256);
-                    else {
-                        constexpr int k = j - NA - NBL;
+                if constexpr (j * NSLOT / NITEM == X) {
+                    if constexpr (j < NX) r1[j] = *reinterpret_cast<const f32x4*>(src1c + (first1 ? a_g1[j] : a_g2[j]) + ci1);
+                    else if constexpr (j < NX + NA) ra[j - NX] = *reinterpret_cast<const f32x4*>(src + (first ? a_g1[j - NX] : a_g2[j - NX]) + ci0);
+                    else if constexpr (j < NX + NA + NBL) bn[(j - NX - NA) / NSLAB][(j - NX - NA) % NSLAB] = *reinterpret_cast<const float4*>(w + (j - NX - NA) * 256);
+                    else if constexpr (j < 2 * NX + NA + NBL) {
+                        constexpr int k = j - NX - NA - NBL;
+                        if ((A_F4 % NTH == 0) || tid + k * NTH < A_F4) *reinterpret_cast<f32x4*>(stn + a_l[k]) = r1[k];
+                    } else {
+                        constexpr int k = j - 2 * NX - NA - NBL;
                         if ((A_F4 % NTH == 0) || tid + k * NTH < A_F4) *reinterpret_cast<f32x4*>(stw + a_l[k]) = ra[k];
                     }
                 }
@@ -250,9 +258,10 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
                 constexpr int lp = decltype(lpc)::value;
                 constexpr int X = q * L + lp;  // block index
                 // next A fragment: (lp+1, q) | (0, q+1) | first fragment of the next chunk
+                // (the first step reads the latter after its barrier: chunk 1 is committed during that step)
                 const float* an_p = (lp + 1 < L) ? st + frag + (lp + 1) * (MS * LDK) + KG * q
                                     : (q + 1 < QW) ? st + frag + KG * (q + 1)
-                                                   : stn + frag;
+                                                   : (FIRST ? st : stn) + frag;
                 const float4 an = *reinterpret_cast<const float4*>(an_p);
                 // the block: component-major over the tiles this A fragment feeds, so that consecutive MFMAs go to
                 // different accumulators (the 16x16x4 MFMA has 40 cycles of dependent latency for 32 of issue); after
@@ -277,20 +286,22 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
             });
         });
         __syncthreads();
+        if constexpr (FIRST) a4 = *reinterpret_cast<const float4*>(stn + frag);
     };
 
     {
-        int i = 0;
-        int sc = 0;  // stage of chunk i
+        step(std::true_type{}, 0, lds, lds + A_FL, lds + 2 * A_FL, bA, bB);
+        int i = 1;
+        int sc = 1;  // stage of chunk i
         for (; i + 1 < nK; i += 2) {
             const int s1 = (sc == 2) ? 0 : sc + 1, s2 = (s1 == 2) ? 0 : s1 + 1;
-            step(i, lds + sc * A_FL, lds + s1 * A_FL, lds + s2 * A_FL, bA, bB);
-            step(i + 1, lds + s1 * A_FL, lds + s2 * A_FL, lds + sc * A_FL, bB, bA);
+            step(std::false_type{}, i, lds + sc * A_FL, lds + s1 * A_FL, lds + s2 * A_FL, bB, bA);
+            step(std::false_type{}, i + 1, lds + s1 * A_FL, lds + s2 * A_FL, lds + sc * A_FL, bA, bB);
             sc = s2;
         }
         if (i < nK) {
             const int s1 = (sc == 2) ? 0 : sc + 1, s2 = (s1 == 2) ? 0 : s1 + 1;
-            step(i, lds + sc * A_FL, lds + s1 * A_FL, lds + s2 * A_FL, bA, bB);
+            step(std::false_type{}, i, lds + sc * A_FL, lds + s1 * A_FL, lds + s2 * A_FL, bB, bA);
         }
     }
 #undef EDMP_W_MFMA
@@ -375,9 +386,10 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
             // the threads of a sample row that share this thread's GroupNorm group: all PPR of them when the workgroup
             // holds one group, else those whose column offset (4 * part) % CG falls into the same GS-wide group
             auto row_group_sum = [&](float x) __attribute__((always_inline)) {
-#pragma unroll
-                for (int m = 1; m < PPR; m <<= 1)
-                    if (GS == CG || (4 * m) % CG < GS) x += __shfl_xor(x, m, 64);
+                static_for<0, 4>([&](auto bc) __attribute__((always_inline)) {
+                    constexpr int m = 1 << decltype(bc)::value;
+                    if constexpr (m < PPR && (GS == CG || (4 * m) % CG < GS)) x = dpp_xor_add<m>(x);
+                });
                 return x;
             };
             constexpr float inv_n = 1.0f / (float)(LOUT * GS);
