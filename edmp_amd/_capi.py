@@ -29,6 +29,8 @@ class EdmpError(RuntimeError):
 _vp, _i, _d = C.c_void_p, C.c_int, C.c_double
 _pd, _pf, _pi32 = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)  # edmp_allreduce_fn(user, hip_stream, sumsq_dev)
+
 # name -> (restype, argtypes); every symbol include/edmp_hip.h declares
 SIGNATURES = {
     "edmp_last_error": (C.c_char_p, []),
@@ -62,6 +64,8 @@ SIGNATURES = {
     "edmp_rng_normal_dev": (_i, [_vp, C.c_uint64, _i, _i, _i, _i, _vp]),
     "edmp_sampler_set_graph": (_i, [_vp, _i]),
     "edmp_q_sample_dev": (_i, [_vp, _vp, _vp, _pi32, _i, _i, _i, _i, _i, _vp, _vp]),
+    "edmp_argmin_dev": (_i, [_vp, _vp, _i, C.POINTER(C.c_int)]),
+    "edmp_sampler_set_allreduce": (_i, [_vp, _vp, _vp]),
     "edmp_prof_enable": (_i, [_vp, _i]),
     "edmp_prof_read": (_i, [_vp, _pd, C.POINTER(C.c_int64), _i]),
     "edmp_prof_ops": (_i, [_vp, _i, C.POINTER(C.c_int), _pd, C.POINTER(C.c_int64), _pd, C.c_char_p]),

@@ -407,23 +407,34 @@ __global__ void mix_gradient_kernel(const float* __restrict__ graw, const double
 }
 
 __global__ void argmin_kernel(const float* __restrict__ v, int n, int* __restrict__ out) {
-    // single wave; first index on ties, NaN never selected unless all NaN (torch.argmin would pick NaN — volumes are finite)
+    // single wave; torch.argmin semantics (lib/guide.py:650): first index on ties, and NaN compares as the smallest
+    // value, so the first NaN row wins if there is one
     int lane = threadIdx.x;
     float best = INFINITY;
     int bi = 0x7fffffff;
+    bool bnan = false;
+    auto better = [](float x, int i, bool xn, float b, int j, bool bn) {
+        if (xn != bn) return xn;             // NaN beats every number
+        if (xn) return i < j;                // both NaN: first index
+        return x < b || (x == b && i < j);   // numbers: smaller, then first index
+    };
     for (int i = lane; i < n; i += 64) {
-        float x = v[i];
-        if (x < best) {
+        const float x = v[i];
+        const bool xn = x != x;
+        if (better(x, i, xn, best, bi, bnan)) {
             best = x;
             bi = i;
+            bnan = xn;
         }
     }
     for (int o = 32; o > 0; o >>= 1) {
-        float ob = __shfl_xor(best, o, 64);
-        int oi = __shfl_xor(bi, o, 64);
-        if (ob < best || (ob == best && oi < bi)) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        const bool on = __shfl_xor((int)bnan, o, 64) != 0;
+        if (better(ob, oi, on, best, bi, bnan)) {
             best = ob;
             bi = oi;
+            bnan = on;
         }
     }
     if (lane == 0) out[0] = (bi == 0x7fffffff) ? 0 : bi;
@@ -611,6 +622,7 @@ extern "C" int edmp_rows_set(edmp_ctx* ctx, const int32_t* row_class, const floa
                              int T) {
     EDMP_REQUIRE(ctx && ctx->guide && ctx->guide->aabb, "edmp_rows_set: call edmp_scene_set first");
     EDMP_REQUIRE(row_class && method && grad_norm && sched && B >= 1, "edmp_rows_set: null argument");
+    EDMP_REQUIRE(T == ctx->guide->T, "edmp_rows_set: guidance_schedule has %d steps, the scene tables %d (the reference indexes both with t-1)", T, ctx->guide->T);
     ctx->epoch++;
     Guide* g = ctx->guide;
     for (int i = 0; i < B; ++i) {
@@ -634,6 +646,19 @@ extern "C" int edmp_rows_set(edmp_ctx* ctx, const int32_t* row_class, const floa
     EDMP_HIP_CHECK(hipMemcpy(g->sched, sched, (size_t)B * T * sizeof(double), hipMemcpyHostToDevice));
     g->B = B;
     g->rows_T = T;
+    return EDMP_OK;
+}
+
+extern "C" int edmp_argmin_dev(edmp_ctx* ctx, const float* v_dev, int n, int* index_host) {
+    EDMP_REQUIRE(ctx && v_dev && index_host && n >= 1, "edmp_argmin_dev: bad arguments");
+    EDMP_HIP_CHECK(hipSetDevice(ctx->device));
+    int* d_idx = nullptr;
+    EDMP_HIP_CHECK(hipMalloc((void**)&d_idx, sizeof(int)));
+    hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(64), 0, ctx->stream, v_dev, n, d_idx);
+    hipError_t e = hipMemcpyAsync(index_host, d_idx, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_idx);
+    EDMP_HIP_CHECK(e);
     return EDMP_OK;
 }
 

@@ -56,6 +56,10 @@ struct Sampler {
     int graph_captures = 0, graph_replays = 0;
     double* qcoef = nullptr;  // [B][2] sqrt(a), sqrt(1 - a) of edmp_q_sample_dev
     int qcoef_cap = 0;
+    // "one logical batch over several GPUs": called between the two halves of every guided step of the device-resident
+    // loop to sum the device scalar sum(g^2) over ranks (lib/guide.py:629 is the only coupling between rows)
+    edmp_allreduce_fn ar_fn = nullptr;
+    void* ar_user = nullptr;
 };
 
 void sampler_destroy(Sampler* s) {
@@ -521,7 +525,14 @@ static int check_loop_state(edmp_ctx* ctx, int B, bool guided) {
     EDMP_REQUIRE(ctx->unet->desc.input_dim == 7 || !guided, "the guide needs 7 joint channels");
     EDMP_REQUIRE(ctx->sampler->T <= ctx->unet->desc.T, "sampler T exceeds the model's time-bias table");
     EDMP_REQUIRE(B >= 1 && B <= ctx->unet->max_batch, "batch %d outside 1..%d", B, ctx->unet->max_batch);
-    if (guided) EDMP_REQUIRE(ctx->guide && ctx->guide->aabb && ctx->guide->row_class, "scene / rows not set");
+    if (guided) {
+        EDMP_REQUIRE(ctx->guide && ctx->guide->aabb && ctx->guide->row_class, "scene / rows not set");
+        // the wave-per-trajectory guide kernel holds one waypoint per lane (+ start and goal): horizon <= 64; the update
+        // kernel reads guidance_schedule[b][t-1] and the obstacle table has one slice per step: both must cover 1..T
+        EDMP_REQUIRE(ctx->unet->desc.horizon <= 64, "guided sampling needs horizon <= 64 (one waypoint per lane), model has %d", ctx->unet->desc.horizon);
+        EDMP_REQUIRE(ctx->guide->rows_T >= ctx->sampler->T, "guidance_schedule covers %d steps, the sampler runs %d", ctx->guide->rows_T, ctx->sampler->T);
+        EDMP_REQUIRE(ctx->guide->T >= ctx->sampler->T, "scene tables cover %d steps, the sampler runs %d", ctx->guide->T, ctx->sampler->T);
+    }
     return EDMP_OK;
 }
 
@@ -581,6 +592,15 @@ static int enqueue_loop(edmp_ctx* ctx, const double* noise_dev, bool use_rng, ui
         const double* z = use_rng ? nullptr : noise_dev + (size_t)(t_hi - t) * n;
         rc = step_a(ctx, s->X, z, B, t, zero_row0, guided, nullptr, nullptr, true, use_rng, seed);
         if (rc) return rc;
+        if (s->ar_fn && guided && guided_step(t)) {
+            // sharded logical batch: this rank's sum(g^2) -> the whole batch's, enqueued by the caller's collective on
+            // the context's stream (stream order is the only synchronisation: no host round trip)
+            rc = s->ar_fn(s->ar_user, (void*)st, guide_sumsq(ctx));
+            if (rc) {
+                set_error("allreduce hook failed with status %d at step t=%d", rc, t);
+                return EDMP_ERR_STATE;
+            }
+        }
         rc = step_b(ctx, s->X, B, t, guided, nullptr, true);
         if (rc) return rc;
     }
@@ -589,7 +609,7 @@ static int enqueue_loop(edmp_ctx* ctx, const double* noise_dev, bool use_rng, ui
 }
 
 static int denoise_loop(edmp_ctx* ctx, const double* noise_dev, bool use_rng, uint64_t seed, int B, const double* start, const double* goal,
-                        int guided, int t_hi, int t_lo, bool init, int zero_row0, double* X_out_dev) {
+                        int guided, int t_hi, int t_lo, bool init, int zero_row0, double* X_out_dev, bool allow_graph = true) {
     int rc = check_loop_state(ctx, B, guided != 0);
     if (rc) return rc;
     EDMP_REQUIRE(noise_dev || use_rng, "null noise pointer");
@@ -615,7 +635,9 @@ static int denoise_loop(edmp_ctx* ctx, const double* noise_dev, bool use_rng, ui
         const char* e = getenv("EDMP_GRAPH");
         s->graph_on = (e && e[0] && e[0] != '0') ? 1 : 0;
     }
-    const bool graph = s->graph_on == 1 && !ctx->prof.on;
+    // a caller-supplied collective is not capturable; segments of a chunked run carry a fresh noise pointer each, so a
+    // captured graph would never be replayed (capture + instantiate + destroy per chunk): they are enqueued directly
+    const bool graph = allow_graph && s->graph_on == 1 && !ctx->prof.on && !s->ar_fn;
     Sampler::GraphKey key;
     if (graph) {
         if (guided) {
@@ -674,7 +696,14 @@ extern "C" int edmp_denoise_guided_rng_dev(edmp_ctx* ctx, uint64_t seed, int B, 
 extern "C" int edmp_denoise_guided_segment_dev(edmp_ctx* ctx, const double* noise_dev, int B, const double* start, const double* goal, int guided,
                                                int t_hi, int t_lo, int init, int zero_row0, double* X_out_dev) {
     EDMP_REQUIRE(ctx && ctx->sampler && noise_dev, "edmp_denoise_guided_segment_dev: bad arguments");
-    return denoise_loop(ctx, noise_dev, false, 0, B, start, goal, guided, t_hi, t_lo, init != 0, zero_row0, X_out_dev);
+    return denoise_loop(ctx, noise_dev, false, 0, B, start, goal, guided, t_hi, t_lo, init != 0, zero_row0, X_out_dev, false);
+}
+
+extern "C" int edmp_sampler_set_allreduce(edmp_ctx* ctx, edmp_allreduce_fn fn, void* user) {
+    EDMP_REQUIRE(ctx && ctx->sampler, "sampler not initialised");
+    ctx->sampler->ar_fn = fn;
+    ctx->sampler->ar_user = user;
+    return EDMP_OK;
 }
 
 extern "C" int edmp_sampler_set_graph(edmp_ctx* ctx, int on) {

@@ -20,6 +20,22 @@ def draw_noise(T: int, batch_size: int, num_channels: int, traj_len: int) -> np.
     return nprng.standard_normal((T + 1, batch_size, num_channels, traj_len))
 
 
+def _startgoal(start, goal, needed: bool):
+    """(7,) f64 start / goal for the C ABI (which reads 7 doubles from each).  The reference allows None when it neither
+    conditions nor guides (diffusion.py:253, 300): zeros stand in there; anything else must have exactly 7 entries."""
+    out = []
+    for name, v in (("start", start), ("goal", goal)):
+        if v is None:
+            if needed:
+                raise ValueError(f"{name} is required when conditioning or guiding")
+            v = np.zeros(7)
+        a = np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(-1))
+        if a.size != 7:
+            raise ValueError(f"{name} must have 7 joint values, got shape {np.shape(v)}")
+        out.append(a)
+    return out
+
+
 class Diffusion:
     """Same constructor / method signatures as the reference ``Diffusion(T, device, variance_thresh=0.02)``."""
 
@@ -125,31 +141,43 @@ class Diffusion:
         ctx = self.ctx
         self._prepare(model, guide, batch_size, guidance_schedule)
         _capi.check(ctx.lib.edmp_sampler_set_condition(ctx.h, 1 if condition else 0))
-        s = np.ascontiguousarray(np.asarray(start, dtype=np.float64).reshape(-1))
-        g = np.ascontiguousarray(np.asarray(goal, dtype=np.float64).reshape(-1))
+        s, g = _startgoal(start, goal, needed=bool(condition) or guide is not None)
+        if int(traj_len) != model.horizon or int(num_channels) != model.input_dim:
+            raise ValueError(f"traj_len/num_channels ({traj_len}, {num_channels}) do not match the model's ({model.horizon}, {model.input_dim})")
+        if not 0 <= int(t_stop) < self.T:
+            raise ValueError(f"t_stop must lie in [0, {self.T}), got {t_stop}")
         out = ctx.empty((batch_size, num_channels, traj_len), torch.float64)
         if allreduce is not None:
             # "one logical batch across GPUs": this rank holds a row shard of a larger reference batch; the only cross-row
             # coupling, the whole-batch sum(g^2) (lib/guide.py:629), is summed over ranks between the two halves of every
-            # guided step.  Device-resident state, one pair of C calls per step.
+            # guided step - INSIDE the device-resident loop: the library calls the hook once per guided step with the
+            # context's stream and the device scalar, the collective is ordered by the stream (no host round trip)
             if noise is None or isinstance(noise, str):
                 raise ValueError("sharded runs take an explicit noise array (this rank's rows of the global stream)")
-            nd = ctx.adopt(noise) if (isinstance(noise, torch.Tensor) and noise.is_cuda) else ctx.to_dev(noise, torch.float64)
-            with torch.cuda.stream(ctx.stream):  # every torch op on the loop state runs on the context's stream
-                X = nd[0].clone()
-                if condition:
-                    X[:, :, 0] = torch.as_tensor(s, device=ctx.device)
-                    X[:, :, -1] = torch.as_tensor(g, device=ctx.device)
-            for t in range(self.T, int(t_stop), -1):
-                _capi.check(ctx.lib.edmp_step_a_dev(ctx.h, ptr(X), ptr(nd[1 + (self.T - t)]), batch_size, t, _capi.as_pd(s), _capi.as_pd(g),
-                                                    1 if zero_row0 else 0, None, None), "edmp_step_a_dev")
-                if guide is not None and (t % 2) < 1 and t >= 5:
-                    # the collective runs with THIS context's stream current: RCCL orders its own stream after the gradient
-                    # kernels and step_b after the collective, with no host synchronisation (gloo's host copy syncs itself)
-                    with torch.cuda.stream(ctx.stream):
-                        allreduce(self.sumsq_tensor())
-                _capi.check(ctx.lib.edmp_step_b_dev(ctx.h, ptr(X), batch_size, t, _capi.as_pd(s), _capi.as_pd(g), None), "edmp_step_b_dev")
-            return ctx.hand_over(X) if return_device else ctx.to_host(X)
+            sumsq = self.sumsq_tensor()
+
+            def _hook(_user, _stream, _ptr):
+                try:
+                    with torch.cuda.stream(ctx.stream):  # RCCL orders itself after the gradient kernels / before step_b
+                        allreduce(sumsq)
+                    return 0
+                except Exception as exc:  # surfaced by the C side as EDMP_ERR_STATE
+                    self._hook_error = exc
+                    return 1
+
+            cb = _capi.ALLREDUCE_FN(_hook)
+            self._hook_error = None
+            _capi.check(ctx.lib.edmp_sampler_set_allreduce(ctx.h, C.cast(cb, C.c_void_p), None))
+            try:
+                res = self.denoise_guided(model, guide, traj_len, num_channels, guidance_schedule, batch_size, start, goal, condition, benchmarking,
+                                          noise=noise, seed=seed, t_stop=t_stop, zero_row0=zero_row0, return_device=return_device)
+            except _capi.EdmpError:
+                if self._hook_error is not None:
+                    raise self._hook_error
+                raise
+            finally:
+                _capi.check(ctx.lib.edmp_sampler_set_allreduce(ctx.h, None, None))
+            return res
         if isinstance(noise, str):
             if noise != "device":
                 raise ValueError("noise must be an array, a device tensor, None (NumPy stream) or 'device'")
@@ -224,8 +252,7 @@ class Diffusion:
         _capi.check(ctx.lib.edmp_sampler_set_condition(ctx.h, 1))
         Xd = ctx.to_dev(np.array(X, dtype=np.float64), torch.float64)  # a fresh device tensor: updated in place below
         zd = ctx.to_dev(np.asarray(z, dtype=np.float64), torch.float64)
-        s = np.ascontiguousarray(np.asarray(start, dtype=np.float64).reshape(-1))
-        g = np.ascontiguousarray(np.asarray(goal, dtype=np.float64).reshape(-1))
+        s, g = _startgoal(start, goal, needed=True)
         eps = ctx.empty((B, Cc, N), torch.float32)
         xpost = ctx.empty((B, Cc, N), torch.float64)
         grad = ctx.empty((B, Cc, N - 2), torch.float64)

@@ -38,11 +38,12 @@ def _comm_device(device=None):
     return torch.device("cpu")
 
 
-def gather_best(local_volume: float, local_index: int, local_traj, success: bool, device=None, group=None):
+def gather_best(local_volume: float, local_index: int, local_traj, success: bool, device=None, group=None, always=False):
     """End-of-sampling exchange.  Returns dict(volume, rank, index, traj (7,50) f64 ndarray, success, n_success).
-    Ties resolve to the lowest rank (= lowest global row index, like torch.argmin over the unsharded batch)."""
+    Ties resolve to the lowest rank (= lowest global row index, like torch.argmin over the unsharded batch).
+    ``always``: run the collectives even in a world of one (exercises the RCCL path on a single-GPU box)."""
     traj = np.asarray(local_traj, dtype=np.float64)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not always):
         return dict(volume=float(local_volume), rank=0, index=int(local_index), traj=traj.copy(), success=bool(success), n_success=int(bool(success)))
     dev = _comm_device(device)
     world = dist.get_world_size(group)
@@ -52,17 +53,18 @@ def gather_best(local_volume: float, local_index: int, local_traj, success: bool
     dist.all_gather(allv, mine, group=group)
     table = torch.stack(allv).cpu().numpy()
     vols = table[:, 0]
-    vols_cmp = np.where(np.isnan(vols), np.inf, vols)
-    owner = int(np.argmin(vols_cmp))  # first minimum -> lowest rank
+    owner = int(np.argmin(vols))  # first minimum -> lowest rank; NaN wins like torch.argmin over the unsharded batch (np.argmin agrees)
     t = torch.from_numpy(traj.copy()).to(dev) if rank == owner else torch.empty(traj.shape, dtype=torch.float64, device=dev)
     dist.broadcast(t, src=owner if group is None else dist.get_global_rank(group, owner), group=group)
     return dict(volume=float(vols[owner]), rank=owner, index=int(table[owner, 1]), traj=t.cpu().numpy(), success=bool(table[owner, 2] > 0),
                 n_success=int((table[:, 2] > 0).sum()))
 
 
-def allreduce_sum_(t: torch.Tensor, group=None):
-    """in-place sum over ranks (the per-guided-step scalar of the 'one logical batch' mode)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+def allreduce_sum_(t: torch.Tensor, group=None, always=False):
+    """in-place sum over ranks (the per-guided-step scalar of the 'one logical batch' mode).  With the nccl backend the
+    collective is enqueued by RCCL behind the CURRENT torch stream's work (Diffusion.denoise_guided makes the context's
+    stream current around the call).  ``always``: issue the collective even in a world of one."""
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or always):
         if dist.get_backend() == "nccl":
             dist.all_reduce(t, group=group)
         else:

@@ -101,6 +101,9 @@ int edmp_guide_gradient_dev(edmp_ctx* ctx, const double* joints_dev, int B, int 
  * volume (B,) f32; the argmin (first on ties) is written to *best_index (host, synchronises) if not NULL */
 int edmp_row_swept_volumes_dev(edmp_ctx* ctx, const double* X_dev, int B, int N, const double* start,
                                const double* goal, float* volumes_dev, int* best_index);
+/* torch.argmin over n f32 values on the device, as choose_best_trajectory uses it (lib/guide.py:650): first index of the
+ * minimum; NaN counts as the smallest value (the first NaN wins).  The selection step of edmp_row_swept_volumes_dev. */
+int edmp_argmin_dev(edmp_ctx* ctx, const float* v_dev, int n, int* index_host);
 
 /* ---- sampler: Diffusion ------------------------------------------------------------------------------ */
 /* replaces Diffusion.__init__/schedule_variance (diffusion/diffusion.py:10-20, 37-49) */
@@ -164,6 +167,16 @@ int edmp_sampler_set_graph(edmp_ctx* ctx, int on);
  * expression (two products, one sum, no FMA contraction), so results are bit-identical to the reference's. */
 int edmp_q_sample_dev(edmp_ctx* ctx, const double* x_dev, const double* eps_dev, const int32_t* t_host, int B, int C, int N,
                       int cumulative, int condition, double* xt_dev, double* mean_dev);
+
+/* ---- one logical batch over several GPUs ------------------------------------------------------------------ */
+/* The reference has no distributed code; its only coupling between batch rows is the whole-batch gradient norm
+ * gradient1 / np.linalg.norm(gradient1) (lib/guide.py:629).  When one reference batch is row-sharded over ranks, the
+ * device-resident loop calls `fn(user, hip_stream, sumsq_dev)` once per guided step, between the gradient kernels
+ * and the state update: the callee must enqueue, ON THAT STREAM, an in-place sum over ranks of the f64 device scalar
+ * (e.g. ncclAllReduce / torch.distributed.all_reduce with that stream current) and return 0.  fn = NULL (default)
+ * restores the single-GPU behaviour.  hipGraph replay is disabled while a hook is installed. */
+typedef int (*edmp_allreduce_fn)(void* user, void* hip_stream, double* sumsq_dev);
+int edmp_sampler_set_allreduce(edmp_ctx* ctx, edmp_allreduce_fn fn, void* user);
 
 /* ---- instrumentation ----------------------------------------------------------------------------------- */
 /* accumulate HIP-event time of the dominant kernel family (the MFMA conv kernels) while enabled */

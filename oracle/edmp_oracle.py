@@ -505,6 +505,24 @@ class UNetOracle:
 # --------------------------------------------------------------------------------------------------------------
 
 
+def denoise_step(model, guide, X, z, t, guidance_schedule, start, goal, sched, condition=True, full=True):
+    """One iteration of the reverse loop (diffusion.py:314-349) from state X (B,C,N) f64 with the step's draw z:
+    dict(x_in, eps, x_post, grad, x_out).  Teacher-forced tests call it on arbitrary states."""
+    beta, alpha, alpha_bar = sched
+    x_in = X.copy() if full else None
+    eps = model(torch.tensor(X, dtype=torch.float32), torch.tensor([t], dtype=torch.float32)).numpy(force=True)
+    X = p_sample_using_posterior(X, t, eps, z, beta, alpha, alpha_bar)
+    x_post = X.copy() if full else None
+    grad = None
+    if (t % 2) < 1 and t >= 5:
+        grad = guide.get_gradient(clip_joints(X[:, :, 1:-1]), start[:], goal[:], t)
+        X[:, :, 1:-1] = X[:, :, 1:-1] - guidance_schedule[:, t - 1, np.newaxis, np.newaxis] * grad
+    if condition:  # diffusion.py:347-349
+        X[:, :, 0] = start[:]
+        X[:, :, -1] = goal[:]
+    return dict(x_in=x_in, eps=eps, x_post=x_post, grad=grad, x_out=X if not full else X.copy())
+
+
 def denoise_guided(
     model, guide, T, traj_len, num_channels, guidance_schedule, batch_size, start, goal, noise=None, trace=None, t_stop=0, condition=True
 ):
@@ -520,17 +538,8 @@ def denoise_guided(
         X[:, :, 0] = start[:]
         X[:, :, -1] = goal[:]
     for t in range(T, t_stop, -1):
-        x_in = X.copy() if trace is not None else None
-        eps = model(torch.tensor(X, dtype=torch.float32), torch.tensor([t], dtype=torch.float32)).numpy(force=True)
-        X = p_sample_using_posterior(X, t, eps, noise[1 + (T - t)], beta, alpha, alpha_bar)
-        x_post = X.copy() if trace is not None else None
-        grad = None
-        if (t % 2) < 1 and t >= 5:
-            grad = guide.get_gradient(clip_joints(X[:, :, 1:-1]), start[:], goal[:], t)
-            X[:, :, 1:-1] = X[:, :, 1:-1] - guidance_schedule[:, t - 1, np.newaxis, np.newaxis] * grad
-        if condition:  # diffusion.py:347-349
-            X[:, :, 0] = start[:]
-            X[:, :, -1] = goal[:]
+        st = denoise_step(model, guide, X, noise[1 + (T - t)], t, guidance_schedule, start, goal, (beta, alpha, alpha_bar), condition, full=trace is not None)
+        X = st["x_out"]
         if trace is not None:
-            trace[t] = dict(x_in=x_in, eps=eps, x_post=x_post, grad=grad, x_out=X.copy())
+            trace[t] = st
     return X.copy()

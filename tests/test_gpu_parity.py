@@ -4,6 +4,7 @@ RMSE <= 1e-4 per step (teacher-forced); individual kernels are 
 import numpy as np
 import pytest
 import torch
+from ctypes import byref, c_int as C_int
 
 from tests.util import FULL_DIMS, T, TINY_DIMS, cfgs_for, maxabs, noise_for, rmse
 
@@ -639,9 +640,53 @@ def test_plain_c_host_through_the_c_abi(golden, tmp_path):
     assert best == ip and np.array_equal(vols, vp)
 
 
-def test_teacher_forced_vs_oracle_at_full_size(oracle):
-    """BASELINE configs[1]/[2] sizes: B = 1024, full 29.9 M-parameter UNet, 6-guide ensemble, 16 obstacles — two
-    teacher-forced reverse steps (one guided) against the CPU oracle, at the north-star tolerance."""
+def _subset_cfgs(cfgs, rows):
+    out = dict(cfgs)
+    for k in ("clearance", "expansion", "guidance_method", "grad_norm", "guidance_schedule", "volume_trust_region"):
+        out[k] = np.ascontiguousarray(np.asarray(cfgs[k])[rows])
+    out["total_batch_size"] = len(rows)
+    return out
+
+
+def _tie_margins(oracle, scene, cfgs, rows, q_rows, start, goal, t, ref_grad_rows):
+    """For rows whose HIP gradient differs from the oracle's by more than the tolerance: the smallest joint perturbation
+    delta (rad) at which the ORACLE's own f32-autograd gradient of that row jumps by more than the tolerance.  The
+    overlap-volume cost is piecewise smooth (arg-min/arg-max box corners, min/max of AABB faces, clamp at 0:
+    lib/guide.py:361-395, 507-537); a jump under a 1e-6 rad perturbation (link corners move <= ~1e-6 m, the size of the
+    float32 rounding envelope of the 7-joint FK chain) means the reference itself sits on a tie there - which branch
+    carries the gradient is decided by the last ulps of sin/cos and the FMA order, on any platform."""
+    go = oracle.GuideOracle(scene, _subset_cfgs(cfgs, rows), len(rows))
+    rs = np.random.RandomState(12345)
+    margins = np.full(len(rows), np.inf)
+    for delta in (1e-7, 3e-7, 1e-6, 3e-6, 1e-5):
+        for _ in range(12):
+            pert = q_rows + delta * rs.choice([-1.0, 1.0], size=q_rows.shape)
+            g = go.raw_gradient(pert, start, goal, t)
+            jump = np.abs(g - ref_grad_rows).reshape(len(rows), -1).max(axis=1) > 1e-4
+            margins = np.where(jump & np.isinf(margins), delta, margins)
+        if np.all(np.isfinite(margins)):
+            break
+    return margins
+
+
+FULL_SIZE_CASES = [
+    # BASELINE config 3 (and 4's per-rank workload): every break-point of the schedules - first step, maximum inflation,
+    # guide 10's expansion segments [80,255) / [20,80), guide 5's clearance ramp, an odd (unguided) step, the last guided step
+    ("c3_six_guides", [1, 2, 3, 4, 5, 10], (255, 254, 200, 129, 128, 80, 20, 6)),
+    # BASELINE config 2 as written
+    ("c2_three_guides", [1, 2, 3], (254, 80)),
+    # BASELINE config 5's guide list: 11 and 13 are grad_norm rows -> the whole-batch sum(g^2) at full size
+    ("c5_eight_guides", [1, 2, 3, 4, 5, 10, 11, 13], (254, 128, 6)),
+]
+
+
+@pytest.mark.parametrize("tag,guides,steps", FULL_SIZE_CASES, ids=[c[0] for c in FULL_SIZE_CASES])
+def test_teacher_forced_vs_oracle_at_full_size(oracle, tag, guides, steps):
+    """BASELINE configs[1..4] sizes: B = 1024, full 29.9 M-parameter UNet, 16 obstacles.  For every listed reverse step t
+    the state X_t is produced by the HIP path itself (free-running from t = 255 with device-resident noise), then ONE
+    step is computed by both sides from that identical (X_t, z_t): eps, posterior, mixed gradient, X_{t-1} at the
+    north-star tolerance.  Rows whose gradient differs are accepted only with proof, from the oracle side, that the
+    reference is discontinuous there (a tie, _tie_margins) - a row that differs without a tie fails the test."""
     from edmp_amd import scenes
     from edmp_amd import weights as W
     from edmp_amd.diffusion import Diffusion
@@ -652,36 +697,52 @@ def test_teacher_forced_vs_oracle_at_full_size(oracle):
     B = 1024
     sd = W.init_state_dict(1, 7, 32, FULL_DIMS)
     net = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, state_dict=sd, max_batch=B)
-    guides = [1, 2, 3, 4, 5, 10]
     cfgs = cfgs_for(guides, 0, rows_per_guide=split_rows(B, len(guides)))
     scene = scenes.random_scene(11, 16)
     guide = IntersectionVolumeGuide(scene, DEV, cfgs, B)
     dif = Diffusion(T, DEV)
     s, gl = scenes.DEFAULT_START, scenes.DEFAULT_GOAL
-    noise = np.random.RandomState(3).standard_normal((3, B, 7, 50))
-    trace = {}
-    oracle.denoise_guided(oracle.UNetOracle(sd), oracle.GuideOracle(scene, cfgs, B), T, 50, 7, cfgs["guidance_schedule"], B, s, gl, noise=noise, trace=trace, t_stop=T - 2)
-    def split_rows_by_flip(a, b):
-        """The overlap-volume gradient is piecewise smooth: where two box corners (or two AABB faces) coincide to
-        float precision, which one carries the gradient is decided by the last ulp of the FK, so any re-implementation
-        (another BLAS, another libm, the reference on CUDA) flips a few waypoints per thousand rows.  Rows are split
-        into "flipped" (some element off by > 1e-4) and regular ones; regular rows must meet the tolerance, flips must
-        be rare."""
-        d = np.abs(np.asarray(a) - np.asarray(b)).reshape(B, -1).max(axis=1)
-        return d <= 1e-4
-
-    for t in (255, 254):
-        st = dif.denoise_step(net, guide, trace[t]["x_in"], noise[1 + (T - t)], t, s, gl, cfgs["guidance_schedule"])
-        assert rmse(st["eps"], trace[t]["eps"]) <= 2e-5, (t, rmse(st["eps"], trace[t]["eps"]))
-        assert rmse(st["x_post"], trace[t]["x_post"]) <= 1e-6
-        if trace[t]["grad"] is not None:
-            ok = split_rows_by_flip(st["grad"], trace[t]["grad"])
-            assert ok.mean() >= 0.995, f"{(~ok).sum()} of {B} rows flipped"
-            assert rmse(st["grad"][ok], trace[t]["grad"][ok]) <= 1e-5
-            assert rmse(st["x_out"][ok], trace[t]["x_out"][ok]) <= 1e-4
-            assert np.median(np.abs(st["x_out"] - trace[t]["x_out"]).reshape(B, -1).max(axis=1)) <= 1e-5
+    noise = np.random.RandomState(3).standard_normal((T + 1, B, 7, 50))
+    om, og = oracle.UNetOracle(sd), oracle.GuideOracle(scene, cfgs, B)
+    sched = oracle.schedule(T)
+    n_flipped, worst_margin = 0, 0.0
+    for t in steps:
+        if t == T:
+            X = np.array(noise[0])
+            X[:, :, 0], X[:, :, -1] = s, gl
         else:
-            assert rmse(st["x_out"], trace[t]["x_out"]) <= 1e-4, (t, rmse(st["x_out"], trace[t]["x_out"]))
+            X = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=s, goal=gl, noise=noise, t_stop=t)
+        assert np.isfinite(X).all(), t
+        z = noise[1 + (T - t)]
+        ref = oracle.denoise_step(om, og, X, z, t, cfgs["guidance_schedule"], s, gl, sched)
+        st = dif.denoise_step(net, guide, X, z, t, s, gl, cfgs["guidance_schedule"])
+        scale = max(1.0, float(np.sqrt(np.mean(ref["eps"] ** 2))))  # random-init weights: |eps| grows along the run
+        assert rmse(st["eps"], ref["eps"]) <= 2e-5 * scale, (tag, t, rmse(st["eps"], ref["eps"]), scale)
+        assert rmse(st["x_post"], ref["x_post"]) <= 1e-6 * scale, (tag, t)
+        if ref["grad"] is None:
+            assert st["grad"] is None
+            assert rmse(st["x_out"], ref["x_out"]) <= 1e-4, (tag, t, rmse(st["x_out"], ref["x_out"]))
+            continue
+        # mixed gradients share the whole-batch norm when grad_norm rows exist: compare the RAW per-row gradient decision
+        # through the mixed one of rows without grad_norm, and all rows after accounting for flips
+        d = np.abs(st["grad"] - ref["grad"]).reshape(B, -1).max(axis=1)
+        gmag = np.abs(ref["grad"]).reshape(B, -1).max(axis=1)
+        flipped = np.flatnonzero(d > 1e-4 + 1e-5 * gmag)
+        ok = np.ones(B, dtype=bool)
+        ok[flipped] = False
+        if len(flipped):
+            assert len(flipped) <= 0.005 * B, f"{tag} t={t}: {len(flipped)} of {B} rows differ"
+            q = oracle.clip_joints(ref["x_post"][:, :, 1:-1])[flipped]
+            sub = oracle.GuideOracle(scene, _subset_cfgs(cfgs, flipped), len(flipped))
+            raw_ref = sub.raw_gradient(q, s, gl, t)
+            margins = _tie_margins(oracle, scene, cfgs, flipped, q, s, gl, t, raw_ref)
+            assert np.all(margins <= 3e-6), f"{tag} t={t}: rows {flipped[margins > 3e-6]} differ from the oracle without a tie (margins {margins})"
+            n_flipped += len(flipped)
+            worst_margin = max(worst_margin, float(margins.max()))
+        assert rmse(st["grad"][ok], ref["grad"][ok]) <= 1e-5 * max(1.0, float(np.median(gmag))), (tag, t)
+        assert rmse(st["x_out"][ok], ref["x_out"][ok]) <= 1e-4, (tag, t, rmse(st["x_out"][ok], ref["x_out"][ok]))
+        assert np.median(np.abs(st["x_out"] - ref["x_out"]).reshape(B, -1).max(axis=1)) <= 1e-5
+    print(f"[{tag}] steps {steps}: {n_flipped} tie-flipped row-steps, largest tie margin {worst_margin:.1e} rad")
 
 
 def test_error_behaviour_through_the_boundary():
@@ -811,3 +872,166 @@ def test_one_logical_batch_sharded_over_two_ranks():
     Xno = dif.denoise_guided(net, g2, 50, 7, cfgs["guidance_schedule"][:6], batch_size=6, start=scenes.DEFAULT_START, goal=scenes.DEFAULT_GOAL,
                              noise=np.ascontiguousarray(noise_for(41, B)[:, :6]), t_stop=T - 10)
     assert maxabs(Xno, Xref[:6]) > 1e-6
+
+
+def _nccl_worker(rank, world, port, q):
+    import functools
+    import os
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+        from edmp_amd import dist as ED
+        from edmp_amd import scenes
+        from edmp_amd import weights as W
+        from edmp_amd.diffusion import Diffusion
+        from edmp_amd.guide import IntersectionVolumeGuide
+        from edmp_amd.temporalunet import TemporalUNet
+
+        # device-tensor collectives of the data path: scalar all-reduce, end-of-sampling all-gather + broadcast
+        x = torch.full((1,), 2.5 + rank, dtype=torch.float64, device="cuda:0")
+        ED.allreduce_sum_(x, always=True)
+        torch.cuda.synchronize()
+        traj = np.full((7, 50), float(rank))
+        best = ED.gather_best(3.0 - rank, 5 + rank, traj, True, device="cuda:0", always=True)
+        # the sharded reverse loop with the RCCL all-reduce enqueued from inside the device-resident loop
+        cfgs = cfgs_for([1, 11, 18, 10], 3)
+        Btot = cfgs["total_batch_size"]
+        lo, hi = ED.shard_rows(Btot, rank, world)
+        sh = ED.shard_guide_cfgs(cfgs, lo, hi)
+        net = TemporalUNet(None, 7, 32, DEV, dims=TINY_DIMS, state_dict=W.init_state_dict(5, 7, 32, TINY_DIMS), max_batch=Btot)
+        guide = IntersectionVolumeGuide(scenes.random_scene(7, 8), DEV, sh, hi - lo)
+        dif = Diffusion(T, DEV)
+        noise = np.ascontiguousarray(noise_for(41, Btot)[:, lo:hi])
+        X = dif.denoise_guided(net, guide, 50, 7, sh["guidance_schedule"], batch_size=hi - lo, start=scenes.DEFAULT_START, goal=scenes.DEFAULT_GOAL,
+                               noise=noise, t_stop=T - 10, zero_row0=(rank == 0), allreduce=functools.partial(ED.allreduce_sum_, always=True))
+        q.put(("ok", rank, float(x.item()), best["rank"], best["index"], best["volume"], float(best["traj"][0, 0]), lo, hi, X))
+        dist.destroy_process_group()
+    except Exception as exc:  # reported to the parent: a second rank on the same GPU is refused by RCCL
+        q.put(("error", rank, repr(exc)))
+
+
+def _spawn(target, world, timeout=300):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = []
+    try:
+        for _ in range(world):
+            out.append(q.get(timeout=timeout))
+    finally:
+        for p in ps:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    return sorted(out, key=lambda o: o[1])
+
+
+def test_rccl_branch_world_size_one():
+    """The `nccl` (= RCCL) branch of edmp_amd.dist on the one GPU a test box has: process group of ONE rank, device
+    tensors, the collectives actually issued (always=True): scalar all-reduce, all-gather + broadcast of the best
+    trajectory, and the per-guided-step all-reduce called from inside the device-resident loop through
+    edmp_sampler_set_allreduce - the result must equal the plain single-process run bit for bit."""
+    from edmp_amd import scenes
+    from edmp_amd import weights as W
+    from edmp_amd.diffusion import Diffusion
+    from edmp_amd.guide import IntersectionVolumeGuide
+    from edmp_amd.temporalunet import TemporalUNet
+
+    out = _spawn(_nccl_worker, 1)
+    assert out[0][0] == "ok", out[0]
+    _, rank, x, brank, bidx, bvol, t00, lo, hi, X = out[0]
+    assert x == 2.5 and (brank, bidx, bvol, t00) == (0, 5, 3.0, 0.0)
+    cfgs = cfgs_for([1, 11, 18, 10], 3)
+    B = cfgs["total_batch_size"]
+    assert (lo, hi) == (0, B)
+    net = TemporalUNet(None, 7, 32, DEV, dims=TINY_DIMS, state_dict=W.init_state_dict(5, 7, 32, TINY_DIMS), max_batch=B)
+    guide = IntersectionVolumeGuide(scenes.random_scene(7, 8), DEV, cfgs, B)
+    Xref = Diffusion(T, DEV).denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=scenes.DEFAULT_START, goal=scenes.DEFAULT_GOAL,
+                                            noise=noise_for(41, B), t_stop=T - 10)
+    assert np.array_equal(X, Xref)
+
+
+def test_rccl_two_ranks_on_one_gpu_or_skip():
+    """Two RCCL ranks need two GPUs; on a one-GPU box RCCL refuses the duplicate device - then this test records the
+    reason and skips.  With >= 2 GPUs visible it would run the sharded loop over a real xGMI all-reduce."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two-GPU variant is covered by scripts/run_scale.sh on the multi-GPU lease (ranks pinned per device)")
+    out = _spawn(_nccl_worker, 2, timeout=120)
+    errs = [o for o in out if o[0] == "error"]
+    if errs:
+        pytest.skip(f"RCCL refuses two ranks on one GPU: {errs[0][2][:200]}")
+    cfgs = cfgs_for([1, 11, 18, 10], 3)
+    assert [o[0] for o in out] == ["ok", "ok"] and out[0][2] == out[1][2] == 6.0  # 2.5 + 3.5
+    assert np.concatenate([out[0][-1], out[1][-1]]).shape[0] == cfgs["total_batch_size"]
+
+
+def test_allreduce_hook_inside_the_device_loop(tiny_net):
+    """edmp_sampler_set_allreduce: the hook is called once per guided step with the context's stream and the device
+    scalar; an identity hook leaves the run bit-identical, a hook that doubles sum(g^2) changes exactly the grad_norm rows."""
+    from edmp_amd import scenes
+    from edmp_amd.diffusion import Diffusion
+    from edmp_amd.guide import IntersectionVolumeGuide
+
+    net, _ = tiny_net
+    cfgs = cfgs_for([1, 11], 2)
+    B = cfgs["total_batch_size"]
+    guide = IntersectionVolumeGuide(scenes.random_scene(7, 8), DEV, cfgs, B)
+    dif = Diffusion(T, DEV)
+    noise = noise_for(5, B)
+    kw = dict(batch_size=B, start=scenes.DEFAULT_START, goal=scenes.DEFAULT_GOAL, noise=noise, t_stop=T - 12)
+    Xref = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], **kw)
+    calls = []
+
+    def ident(t):
+        calls.append(int(t.numel()))
+        return t
+
+    X1 = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], allreduce=ident, **kw)
+    assert np.array_equal(X1, Xref) and len(calls) == 6 and set(calls) == {1}  # t = 254, 252, ..., 244
+
+    def double(t):
+        t.mul_(2.0)
+        return t
+
+    X2 = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], allreduce=double, **kw)
+    gn = np.asarray(cfgs["grad_norm"]) > 0
+    assert np.array_equal(X2[~gn], Xref[~gn]) and not np.array_equal(X2[gn], Xref[gn])
+
+    def boom(t):
+        raise RuntimeError("collective failed")
+
+    with pytest.raises(RuntimeError, match="collective failed"):
+        dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], allreduce=boom, **kw)
+    assert np.array_equal(dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], **kw), Xref)  # hook removed, state usable
+
+
+def test_best_trajectory_nan_semantics():
+    """torch.argmin (lib/guide.py:650) treats NaN as the smallest value: the first NaN row wins; edmp's argmin kernel and
+    the cross-rank gather follow it."""
+    from edmp_amd import _capi
+    from edmp_amd.runtime import get_context, ptr
+
+    ctx = get_context(DEV)
+    lib = ctx.lib
+    for vals, want in (([3.0, 1.0, 2.0, 1.0], 1), ([3.0, float("nan"), 0.5, float("nan")], 1), ([float("nan")] * 3, 0), ([float("inf"), 5.0], 1)):
+        v = ctx.to_dev(np.asarray(vals, dtype=np.float32), torch.float32)
+        out = C_int()
+        _capi.check(lib.edmp_argmin_dev(ctx.h, ptr(v), len(vals), byref(out)))
+        ctx.sync()
+        assert out.value == want == int(torch.argmin(torch.tensor(vals)))
