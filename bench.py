@@ -41,14 +41,16 @@ def effective_cores() -> int:
 
 
 def pmc_traffic():
-    """HBM MB per conv-family launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_hbm_traffic.json,
-    produced by scripts/pmc_unet_forward.py + scripts/summarize_pmc.py).  Counters cannot be read live in bench.py."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
-            d = json.load(f)["conv_family"]
-        return {"hbm_MB_per_launch": d["hbm_MB_per_launch"], "hbm_bytes_per_traj_step": d["hbm_bytes_per_traj_step"], "source": "profiles/r01_pmc_hbm_traffic.json (PMC pass, not live)"}
-    except Exception:
-        return None
+    """HBM MB per conv-family launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_hbm_traffic.json, else
+    round 1's; produced by scripts/pmc_unet_forward.py + scripts/summarize_pmc.py).  Counters cannot be read live."""
+    for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)["conv_family"]
+            return {"hbm_MB_per_launch": d["hbm_MB_per_launch"], "hbm_bytes_per_traj_step": d["hbm_bytes_per_traj_step"], "source": f"profiles/{name} (PMC pass, not live)"}
+        except Exception:
+            continue
+    return None
 
 
 def traffic_bytes_per_launch(detail):
@@ -62,7 +64,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1024, help="rows per GPU")
-    ap.add_argument("--guides", type=str, default="1,2,3,4,5,10")
+    ap.add_argument("--guides", type=str, default="1,2,3,4,5,10", help="guide ensemble, e.g. 1,2,3 (BASELINE config 2) or 1,2,3,4,5,10,11,13 (config 5)")
+    ap.add_argument("--logical-batch", action="store_true",
+                    help="BASELINE config 5 semantics: the ranks hold row shards of ONE reference batch of gpus x batch rows; sum(g^2) is all-reduced "
+                         "over RCCL once per guided step from inside the device-resident loop (instead of independent replicas)")
     ap.add_argument("--obstacles", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the instrumented (HIP-event) pass")
@@ -85,6 +90,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(dev))
         else:
             dist.init_process_group(backend)
+    elif args.logical_batch:
+        # a world of one still runs the per-guided-step RCCL all-reduce: N = 1 then measures the hook + collective launch cost
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": torch.device(dev)} if backend == "nccl" else {}))
 
     from edmp_amd import dist as ED
     from edmp_amd import guide_cfg as GC
@@ -95,8 +105,15 @@ def main():
 
     B = args.batch
     guides = [int(g) for g in args.guides.split(",")]
-    cfgs = GC.build_guide_cfgs([GC.catalog_guide_dict(g) for g in guides], 0, T, rows_per_guide=GC.split_rows(B, len(guides)))
-    scene = scenes.random_scene(11 + rank, args.obstacles)  # every rank = its own planning problem replica
+    logical = bool(args.logical_batch)
+    if logical:
+        # one reference batch of world*B rows, guide g owning a contiguous row block; rank r holds rows [r*B, (r+1)*B)
+        full = GC.build_guide_cfgs([GC.catalog_guide_dict(g) for g in guides], 0, T, rows_per_guide=GC.split_rows(world * B, len(guides)))
+        cfgs = ED.shard_guide_cfgs(full, rank * B, (rank + 1) * B)
+        scene = scenes.random_scene(11, args.obstacles)  # one planning problem for the whole batch
+    else:
+        cfgs = GC.build_guide_cfgs([GC.catalog_guide_dict(g) for g in guides], 0, T, rows_per_guide=GC.split_rows(B, len(guides)))
+        scene = scenes.random_scene(11 + rank, args.obstacles)  # every rank = its own planning problem replica
     start, goal = scenes.DEFAULT_START, scenes.DEFAULT_GOAL
 
     net = TemporalUNet(None, C, 32, dev, dims=FULL_DIMS, seed=1, max_batch=B)
@@ -107,8 +124,14 @@ def main():
     noise = ctx.to_dev(noise_host, torch.float64)
     ctx.sync()
 
+    import functools
+
+    # logical-batch mode issues the collective even in a world of one, so that N = 1 measures the hook + RCCL launch cost
+    ar = functools.partial(ED.allreduce_sum_, always=(world > 1 or (dist.is_available() and dist.is_initialized()))) if logical else None
+
     def one_call():
-        X = dif.denoise_guided(net, guide, N, C, cfgs["guidance_schedule"], batch_size=B, start=start, goal=goal, noise=noise, return_device=True)
+        X = dif.denoise_guided(net, guide, N, C, cfgs["guidance_schedule"], batch_size=B, start=start, goal=goal, noise=noise, return_device=True,
+                               allreduce=ar, zero_row0=(rank == 0 or not logical))
         vols, idx = guide.row_swept_volumes(start, goal, X)  # synchronises (argmin comes back to the host)
         traj = X[idx].cpu().numpy()
         ok = ED.geometric_success(float(vols[idx]), traj)
@@ -153,7 +176,8 @@ def main():
             "config": {
                 "workload": f"denoise_guided T={T} N={N} batch={B}/GPU, {len(guides)}-guide ensemble {guides}, {args.obstacles}-cuboid synthetic scene, full TemporalUNet (29.9M params, random init), f64 state / f32 denoiser+guide",
                 "global_batch": world * B,
-                "parallelism": f"row-sharded replicas x{world}, end-of-sampling RCCL gather" if world > 1 else "single GPU",
+                "parallelism": (f"one logical batch of {world * B} rows row-sharded x{world}: RCCL all-reduce of sum(g^2) per guided step inside the device loop + end-of-sampling gather"
+                                if logical else (f"row-sharded replicas x{world}, end-of-sampling RCCL gather" if world > 1 else "single GPU")),
             },
             "best": {"rank": best["rank"], "row": best["index"], "swept_volume": best["volume"], "geometric_success_proxy": best["success"],
                      "note": "random-init denoiser: the proxy (zero t=0 swept AABB volume + joint limits) is expected to be false; reported, never gated"},
@@ -161,7 +185,7 @@ def main():
         }
 
     # ---- informative: whole-scene wall time when the noise is NOT pre-resident (never `value`) -------------------------
-    if world == 1 and rank == 0:
+    if world == 1 and rank == 0 and not logical:
         def scene_time(**kw):
             t1 = time.perf_counter()
             X = dif.denoise_guided(net, guide, N, C, cfgs["guidance_schedule"], batch_size=B, start=start, goal=goal, return_device=True, **kw)
@@ -179,35 +203,76 @@ def main():
             "traj_steps_per_s": {"numpy_stream": B * T / t_np, "device_noise": B * T / t_dev},
         }
 
-    # ---- roofline of the dominant kernel family (fp32-MFMA implicit-GEMM conv), N=1 only -------------------------
+    # ---- roofline of the dominant kernel family (fp32-MFMA conv kernels of the UNet), N=1 only ----------------------
+    # Two extra, instrumented calls with HIP events on the context's stream:
+    #   pass A (edmp_prof_enable 2): ONE event pair around the whole UNet layer program of every reverse step -> the conv
+    #          family's time per call with negligible overhead (510 events per call); like rocprofv3's back-to-back kernel
+    #          trace it contains the dispatch gaps between the program's dependent launches.  conv_ms <= ms_per_step.
+    #   pass B (edmp_prof_enable 1): one pair around EVERY conv launch, read per program op (edmp_prof_ops).  The ~26 k
+    #          extra events cost several us per launch, so pass B only supplies each kernel's share: the measured
+    #          per-launch overhead (sum of pass B - pass A, divided by the launches) is subtracted from every bracket.
+    # FLOPs are the EXECUTED ones (taps that fall into the zero padding are never issued); the nominal SURVEY 8(d)
+    # figure is reported next to it.
     if world == 1 and rank == 0 and not args.no_roofline:
-        ctx.prof(True)
+        ctx.prof(2)
         ctx.prof_read(reset=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
         one_call()
+        torch.cuda.synchronize()
+        passA_wall_ms = 1e3 * (time.perf_counter() - t1)
         conv_ms, launches = ctx.prof_read(reset=True)
-        ctx.prof(False)
+        ctx.prof(1)
+        one_call()
+        ops = ctx.prof_ops()
+        ev_ms, launches_b = ctx.prof_read(reset=True)
+        ctx.prof(0)
+        ms_step = 1e3 * dt / args.steps
+        over_us = 1e3 * (ev_ms - conv_ms) / max(launches_b, 1)  # event overhead per bracketed launch in pass B
         nominal, executed = net.flops_per_trajectory()
-        conv_nominal = nominal - 2.0 * N * C * FULL_DIMS[0]  # the 1x1 head is a separate VALU kernel
-        conv_exec = executed - 2.0 * N * C * FULL_DIMS[0]
-        ach = conv_nominal * B * T / (conv_ms * 1e-3) / 1e12
+        head = 2.0 * N * C * FULL_DIMS[0]  # the 1x1 head runs inside the (VALU) posterior kernel
+        conv_nominal, conv_exec = nominal - head, executed - head
+        table = {}
+        for name, calls, ms, fl in ops:
+            if calls == 0:
+                continue
+            r = table.setdefault(name, {"launches": 0, "ms": 0.0, "flop": 0.0})
+            r["launches"] += calls
+            r["ms"] += max(ms - 1e-3 * over_us * calls, 0.0)
+            r["flop"] += fl * B * calls
+        rows = []
+        for name, r in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
+            tf = r["flop"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
+            rows.append({"kernel": name, "launches": r["launches"], "avg_us": 1e3 * r["ms"] / r["launches"], "share": r["ms"] / conv_ms if conv_ms else 0.0,
+                         "executed_tflops": tf, "frac": tf / PEAK_F32_MFMA_TFLOPS})
+        ach = conv_exec * B * T / (conv_ms * 1e-3) / 1e12
+        tb = traffic_bytes_per_launch(pmc_traffic())
+        avg_s = 1e-3 * conv_ms / max(launches, 1)
         out["roofline"] = {
-            "kernel": "fp32-MFMA conv family: edmp::rcb_conv_kernel / rcb_rows_kernel (Conv1d k5 + GroupNorm + Mish fused) + edmp::conv_mfma_kernel (k1/k3s2/convT k4s2)",
+            "kernel": "fp32-MFMA conv family of the TemporalUNet: edmp::wide_conv_kernel (position-tile Conv1d k5 + GroupNorm + Mish, k3s2, ConvTranspose k4s2; "
+                      "128..512 channels) + edmp::rcb_block_kernel / rcb_rows_kernel / conv_mfma_kernel (32/64-channel levels)",
             "bound": "mfma",
             "achieved": ach,
             "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s",
             "frac": ach / PEAK_F32_MFMA_TFLOPS,
-            "traffic": traffic_bytes_per_launch(pmc_traffic()),  # HBM bytes per conv launch (PMC FETCH_SIZE x2 + WRITE_SIZE passes)
+            "flops": "executed (padding taps never issued)",
+            "traffic": tb,  # HBM bytes per conv launch (PMC FETCH_SIZE x2 + WRITE_SIZE passes, committed under profiles/)
             "traffic_detail": pmc_traffic(),
-            # north-star asks for the HBM fraction too: PMC bytes per launch / measured average launch duration vs 8 TB/s
-            "hbm": (lambda tb: None if tb is None else {"achieved": tb / (1e-3 * conv_ms / max(launches, 1)) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                                         "frac": tb / (1e-3 * conv_ms / max(launches, 1)) / 1e9 / 8000.0})(traffic_bytes_per_launch(pmc_traffic())),
-            "achieved_executed": conv_exec * B * T / (conv_ms * 1e-3) / 1e12,
+            # north-star asks for the HBM fraction too: PMC bytes per launch / average launch duration vs 8 TB/s
+            "hbm": None if tb is None else {"achieved": tb / avg_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": tb / avg_s / 1e9 / 8000.0},
+            "achieved_nominal": conv_nominal * B * T / (conv_ms * 1e-3) / 1e12,
             "launches": launches,
             "avg_launch_us": 1e3 * conv_ms / max(launches, 1),
-            "flops_per_launch_nominal": conv_nominal * B * T / max(launches, 1),
+            "flops_per_launch_executed": conv_exec * B * T / max(launches, 1),
             "conv_ms_per_call": conv_ms,
-            "note": "achieved = nominal (every tap counted, SURVEY 8d) conv FLOPs / summed HIP-event time of the conv launches of one denoise_guided call; achieved_executed counts only taps not in the zero padding",
+            "conv_share_of_step": conv_ms / ms_step,
+            "timing": {"ms_per_step_timed": ms_step, "passA_program_brackets_conv_ms": conv_ms, "passA_wall_ms": passA_wall_ms, "passB_per_launch_brackets_ms": ev_ms,
+                       "passB_event_overhead_us_per_launch": over_us},
+            "per_kernel": rows,
+            "note": "achieved = executed conv FLOPs of one denoise_guided call / conv_ms_per_call (one HIP-event pair around each reverse step's layer program: "
+                    "includes the inter-kernel dispatch gaps, like rocprofv3's back-to-back kernel trace); per_kernel rows = per-launch brackets minus the measured "
+                    "event overhead per launch; achieved_nominal counts every tap (SURVEY 8d)",
         }
 
     # ---- CPU baseline: the oracle (port of the reference) on this box's host cores, bounded sample -----------------
@@ -233,7 +298,7 @@ def main():
         }
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 

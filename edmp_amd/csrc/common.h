@@ -39,7 +39,7 @@ struct Sampler;  // sampler.hip
 // per-launch timing of the UNet layer program (HIP events on the context's stream around every conv-family launch),
 // switched on by edmp_prof_enable for bench.py's roofline pass; folded per program op by prof_fold()
 struct Prof {
-    bool on = false;
+    int on = 0;  // 0 off | 1 one event pair per conv launch (per-op table) | 2 one pair around the whole layer program (total)
     struct Pend {
         hipEvent_t a, b;
         int op;

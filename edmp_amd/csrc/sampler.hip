@@ -753,7 +753,7 @@ extern "C" int edmp_rng_normal_dev(edmp_ctx* ctx, uint64_t seed, int step_index,
 
 extern "C" int edmp_prof_enable(edmp_ctx* ctx, int on) {
     EDMP_REQUIRE(ctx, "null ctx");
-    ctx->prof.on = on != 0;
+    ctx->prof.on = on;
     return EDMP_OK;
 }
 

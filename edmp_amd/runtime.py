@@ -96,8 +96,9 @@ class Context:
             _capi.check(self.lib.edmp_sampler_init(self.h, int(T), float(variance_thresh)), "edmp_sampler_init")
             self.sampler_T = key
 
-    def prof(self, on: bool):
-        _capi.check(self.lib.edmp_prof_enable(self.h, 1 if on else 0))
+    def prof(self, on):
+        """0/False off, 1/True per-launch event brackets, 2 one bracket around the whole UNet layer program."""
+        _capi.check(self.lib.edmp_prof_enable(self.h, int(on)))
 
     def prof_read(self, reset=True):
         ms = C.c_double()

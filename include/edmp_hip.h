@@ -179,7 +179,10 @@ typedef int (*edmp_allreduce_fn)(void* user, void* hip_stream, double* sumsq_dev
 int edmp_sampler_set_allreduce(edmp_ctx* ctx, edmp_allreduce_fn fn, void* user);
 
 /* ---- instrumentation ----------------------------------------------------------------------------------- */
-/* accumulate HIP-event time of the dominant kernel family (the MFMA conv kernels) while enabled */
+/* accumulate HIP-event time of the dominant kernel family (the MFMA conv kernels of the UNet layer program) while enabled:
+ * on = 1: one event pair around every conv launch (per-op table, edmp_prof_ops; ~2 events of overhead per launch);
+ * on = 2: one event pair around the whole layer program of each reverse step (the family's total, negligible overhead);
+ * on = 0: off.  Events are recorded on the context's stream. */
 int edmp_prof_enable(edmp_ctx* ctx, int on);
 /* total ms and launch count of the MFMA conv kernels since the last reset (synchronises) */
 int edmp_prof_read(edmp_ctx* ctx, double* conv_ms, int64_t* conv_launches, int reset);

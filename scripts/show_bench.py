@@ -1,0 +1,22 @@
+#!/usr/bin/env python
+"""Pretty-print a bench.py JSON line (file argument or stdin): headline, roofline summary, per-kernel table."""
+import json
+import sys
+
+txt = open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read()
+lines = [l for l in txt.strip().splitlines() if l.startswith("{")]
+if not lines:
+    print("no JSON line found; tail of input:\n" + txt[-600:])
+    sys.exit(1)
+d = json.loads(lines[-1])
+print(f"value {d['value']:.0f} {d['unit']}  ms_per_step {d['ms_per_step']:.2f}  n_gpus {d['n_gpus']}  | {d['config']['parallelism'][:100]}")
+r = d.get("roofline")
+if r:
+    print(f"roofline: executed {r['achieved']:.1f} TF/s = {r['frac']:.3f} of {r['peak']}; nominal {r['achieved_nominal']:.1f}; conv {r['conv_ms_per_call']:.1f} ms "
+          f"({r['conv_share_of_step']:.3f} of the step) over {r['launches']} launches, avg {r['avg_launch_us']:.2f} us; timing {r['timing']}")
+    for row in r["per_kernel"]:
+        print(f"  {row['kernel']:46s} n={row['launches']:5d} avg {row['avg_us']:7.2f} us share {row['share']:.3f} {row['executed_tflops']:6.1f} TF frac {row['frac']:.3f}")
+if "cpu_baseline" in d:
+    print("cpu_baseline:", d["cpu_baseline"])
+if "end_to_end_scene_seconds" in d:
+    print("end_to_end:", d["end_to_end_scene_seconds"])
