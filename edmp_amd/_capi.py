@@ -64,6 +64,8 @@ SIGNATURES = {
     "edmp_rng_normal_dev": (_i, [_vp, C.c_uint64, _i, _i, _i, _i, _vp]),
     "edmp_sampler_set_graph": (_i, [_vp, _i]),
     "edmp_q_sample_dev": (_i, [_vp, _vp, _vp, _pi32, _i, _i, _i, _i, _i, _vp, _vp]),
+    "edmp_unet_slot": (_i, [_vp, C.c_uint64]),
+    "edmp_guide_slot": (_i, [_vp, C.c_uint64]),
     "edmp_argmin_dev": (_i, [_vp, _vp, _i, C.POINTER(C.c_int)]),
     "edmp_sampler_set_allreduce": (_i, [_vp, _vp, _vp]),
     "edmp_prof_enable": (_i, [_vp, _i]),

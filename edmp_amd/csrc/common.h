@@ -70,8 +70,15 @@ struct edmp_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;  // independent branch of the UNet (residual 1x1 convs) runs here
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    edmp::UNet* unet = nullptr;
-    edmp::Guide* guide = nullptr;
+    edmp::UNet* unet = nullptr;    // the CURRENT model (slot unet_key)
+    edmp::Guide* guide = nullptr;  // the CURRENT scene + rows (slot guide_key)
+    // resident, not current, most recently used first: a caller that alternates between a few models / per-scene guides
+    // (the reference keeps one guide object per scene, infer_serial.py:112) switches by key instead of re-uploading
+    // 120 MB of weights or rebuilding the obstacle table
+    uint64_t unet_key = 0, guide_key = 0;
+    std::vector<std::pair<uint64_t, edmp::UNet*>> unet_slots;
+    std::vector<std::pair<uint64_t, edmp::Guide*>> guide_slots;
+    int unet_cap = 3, guide_cap = 8;  // resident objects per context, the current one included
     edmp::Sampler* sampler = nullptr;
     edmp::Prof prof;
     uint64_t epoch = 0;  // bumped whenever device pointers / tables a captured hipGraph baked in may have changed

@@ -428,6 +428,8 @@ extern "C" void edmp_ctx_destroy(edmp_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     unet_destroy(ctx->unet);
     guide_destroy(ctx->guide);
+    for (auto& e : ctx->unet_slots) unet_destroy(e.second);
+    for (auto& e : ctx->guide_slots) guide_destroy(e.second);
     sampler_destroy(ctx->sampler);
     for (auto& e : ctx->prof.pending) {
         (void)hipEventDestroy(e.a);
@@ -445,6 +447,40 @@ extern "C" void edmp_ctx_destroy(edmp_ctx* ctx) {
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
+}
+
+// make slot `key` the current one: park the current object (most recently used first), fetch the slot if resident
+template <class T, class D>
+static int select_slot(std::vector<std::pair<uint64_t, T*>>& slots, T*& cur, uint64_t& cur_key, uint64_t key, int cap, D destroy) {
+    if (key == cur_key) return cur ? 1 : 0;
+    if (cur) slots.insert(slots.begin(), {cur_key, cur});
+    cur = nullptr;
+    cur_key = key;
+    for (size_t i = 0; i < slots.size(); ++i)
+        if (slots[i].first == key) {
+            cur = slots[i].second;
+            slots.erase(slots.begin() + i);
+            break;
+        }
+    while ((int)slots.size() > std::max(cap - 1, 0)) {  // least recently used goes first
+        destroy(slots.back().second);
+        slots.pop_back();
+    }
+    return cur ? 1 : 0;
+}
+
+extern "C" int edmp_unet_slot(edmp_ctx* ctx, uint64_t key) {
+    if (!ctx) return EDMP_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return EDMP_ERR_HIP;
+    ctx->epoch++;
+    return select_slot(ctx->unet_slots, ctx->unet, ctx->unet_key, key, ctx->unet_cap, unet_destroy);
+}
+
+extern "C" int edmp_guide_slot(edmp_ctx* ctx, uint64_t key) {
+    if (!ctx) return EDMP_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return EDMP_ERR_HIP;
+    ctx->epoch++;
+    return select_slot(ctx->guide_slots, ctx->guide, ctx->guide_key, key, ctx->guide_cap, guide_destroy);
 }
 
 extern "C" int edmp_ctx_set_stream(edmp_ctx* ctx, void* hip_stream) {

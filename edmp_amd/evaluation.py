@@ -101,8 +101,16 @@ def geometric_success(trajectory, obstacle_config, substeps: int = 4, link_mesh_
     return dict(success=bool(within and first < 0), first_collision_waypoint=first, within_limits=within)
 
 
+# the fixed flange / hand chain behind joint 7: rows 8-10 of the reference's modified-DH table [a, d, alpha, theta]
+# (lib/guide.py:36-38), used only by get_end_effector_transform (lib/guide.py:100-116)
+EE_STATIC_DH = ((0.0, 0.107, 0.0, 0.0), (0.0, 0.0, 0.0, -np.pi / 4), (0.0, 0.1034, 0.0, 0.0))
+
+
 def end_effector_positions(trajectory):
-    """(N, 3) flange-frame origins (frame 7 of the DH chain), used by the path-length metric (lib/metrics.py)."""
+    """(N, 3) end-effector positions as lib/metrics.py computes them: the translation of
+    IntersectionVolumeGuide.get_end_effector_transform (lib/guide.py:100-116), i.e. ALL TEN modified-DH rows - the seven
+    joints followed by the fixed rows d = 0.107, theta = -pi/4, d = 0.1034 (0.21 m beyond the joint-7 frame).
+    float64 here, float32 in the reference: agrees to ~1e-7 m (pinned by tests/golden/g13_metrics.npz)."""
     tr = np.asarray(trajectory, dtype=np.float64)
     pts = []
     for i in range(tr.shape[1]):
@@ -110,38 +118,47 @@ def end_effector_positions(trajectory):
         for j in range(7):
             a, d, al = franka.DH_A_D_ALPHA[j]
             T = T @ _dh(a, d, al, tr[j, i])
+        for a, d, al, th in EE_STATIC_DH:
+            T = T @ _dh(a, d, al, th)
         pts.append(T[:3, 3])
     return np.array(pts)
 
 
 def path_lengths(trajectory) -> dict:
-    """joint-space and end-effector path length (lib/metrics.py:47-80 computes both)."""
+    """MetricsCalculator.path_length_metric (lib/metrics.py:32-45): joint-space and end-effector path length."""
     tr = np.asarray(trajectory, dtype=np.float64)
     ee = end_effector_positions(tr)
-    return dict(joint=float(np.sum(np.linalg.norm(np.diff(tr, axis=1), axis=0))), end_effector=float(np.sum(np.linalg.norm(np.diff(ee, axis=0), axis=1))))
+    return dict(joint=float(np.sum(np.linalg.norm(np.diff(tr.T, 1, axis=0), axis=1))), end_effector=float(np.sum(np.linalg.norm(np.diff(ee, 1, axis=0), axis=1))))
 
 
 def sparc(speed_profile, fs: float, padlevel: int = 4, fc: float = 10.0, amp_th: float = 0.05) -> float:
-    """Spectral arc length smoothness (Balasubramanian et al. 2015; the reference vendors the authors' code as
-    mpinets/third_party/sparc.py and calls it from lib/metrics.py:11-45).  More negative = less smooth."""
+    """Spectral arc length smoothness (Balasubramanian et al. 2015): the value `MetricsCalculator.sparc`
+    (lib/metrics.py:47-125, a restatement of mpinets/third_party/sparc.py) returns first.  More negative = less smooth;
+    an all-zero profile returns 0 like the reference."""
     v = np.asarray(speed_profile, dtype=np.float64)
-    nfft = int(2 ** (np.ceil(np.log2(len(v))) + padlevel))
+    if np.allclose(v, 0):
+        return 0.0
+    nfft = int(pow(2, np.ceil(np.log2(len(v))) + padlevel))
     f = np.arange(0, fs, fs / nfft)
     Mf = np.abs(np.fft.fft(v, nfft))
-    Mf = Mf / max(Mf.max(), 1e-300)
-    sel = f <= fc
+    Mf = Mf / Mf.max()
+    sel = np.nonzero(f <= fc)[0]
     f_sel, Mf_sel = f[sel], Mf[sel]
     idx = np.nonzero(Mf_sel >= amp_th)[0]
-    if idx.size == 0:
-        return 0.0
     f_sel, Mf_sel = f_sel[idx[0] : idx[-1] + 1], Mf_sel[idx[0] : idx[-1] + 1]
-    if f_sel.size < 2:
-        return 0.0
     return float(-np.sum(np.sqrt((np.diff(f_sel) / (f_sel[-1] - f_sel[0])) ** 2 + np.diff(Mf_sel) ** 2)))
 
 
-def smoothness(trajectory, dt: float = 0.1) -> float:
-    """SPARC of the joint-space speed profile of a (7, N) trajectory."""
+def smoothness_metric(trajectory, dt: float = 0.1) -> tuple:
+    """MetricsCalculator.smoothness_metric (lib/metrics.py:11-30): (joint SPARC, end-effector SPARC) of the speed
+    profiles ||diff / dt|| of the (7, N) joint trajectory and of its end-effector positions."""
     tr = np.asarray(trajectory, dtype=np.float64)
-    speed = np.linalg.norm(np.diff(tr, axis=1), axis=0) / dt
-    return sparc(speed, 1.0 / dt)
+    js = np.linalg.norm(np.diff(tr.T, n=1, axis=0) / dt, axis=1)
+    ee = end_effector_positions(tr)
+    es = np.linalg.norm(np.diff(ee, n=1, axis=0) / dt, axis=1)
+    return sparc(js, 1.0 / dt), sparc(es, 1.0 / dt)
+
+
+def smoothness(trajectory, dt: float = 0.1) -> float:
+    """joint-space SPARC of a (7, N) trajectory (first component of smoothness_metric)."""
+    return smoothness_metric(trajectory, dt)[0]

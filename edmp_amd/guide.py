@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _capi, franka
-from .runtime import get_context, ptr
+from .runtime import get_context, ptr, new_slot_key
 
 
 def row_classes(clearance: np.ndarray, expansion: np.ndarray):
@@ -60,6 +60,7 @@ class IntersectionVolumeGuide:
         self._sf = np.ascontiguousarray(franka.static_frames())
         self._sched = np.ascontiguousarray(np.asarray(guide_cfgs["guidance_schedule"], dtype=np.float64))
         self._rows_token = None
+        self._slot = new_slot_key()
         self._bind()
 
     # ---- binding -----------------------------------------------------------------------------------------------
@@ -67,6 +68,14 @@ class IntersectionVolumeGuide:
         ctx = self.ctx
         if ctx.bound_guide is self:
             return
+        # switch to this object's resident slot; the scene tables / row arrays are rebuilt only if the slot is empty
+        have = ctx.lib.edmp_guide_slot(ctx.h, self._slot)
+        if have < 0:
+            _capi.check(have, "edmp_guide_slot")
+        if have == 1:
+            ctx.bound_guide = self
+            return
+        ctx.bound_guide = None
         no = self.obstacle_config.shape[0]
         _capi.check(
             ctx.lib.edmp_scene_set(ctx.h, _capi.as_pd(self.obstacle_config), no, _capi.as_pd(self._cls_clr), _capi.as_pd(self._cls_exp),

@@ -123,6 +123,15 @@ class Context:
         return out
 
 
+_slot_counter = [0]
+
+
+def new_slot_key() -> int:
+    """process-unique non-zero key of a model / guide object's resident slot (edmp_unet_slot / edmp_guide_slot)."""
+    _slot_counter[0] += 1
+    return _slot_counter[0]
+
+
 def get_context(device) -> Context:
     idx = _device_index(device)
     if idx not in _contexts:

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _capi, weights
-from .runtime import get_context, ptr
+from .runtime import get_context, new_slot_key, ptr
 
 
 class TemporalUNet:
@@ -54,6 +54,7 @@ class TemporalUNet:
                 raise ValueError(f"{k}: shape {tuple(v.shape)} != expected {tuple(shp)}")
             flat.append(v.reshape(-1))
         self._flat = np.ascontiguousarray(np.concatenate(flat))
+        self._slot = new_slot_key()
         self._bind()
 
     def _desc(self):
@@ -68,6 +69,14 @@ class TemporalUNet:
         ctx = self.ctx
         if ctx.bound_model is self:
             return
+        # switch the context to this object's resident slot; only an empty slot (first use, or evicted) uploads the weights
+        have = ctx.lib.edmp_unet_slot(ctx.h, self._slot)
+        if have < 0:
+            _capi.check(have, "edmp_unet_slot")
+        if have == 1:
+            ctx.bound_model = self
+            return
+        ctx.bound_model = None
         d = self._desc()
         n = ctx.lib.edmp_unet_param_count(C.byref(d))
         if n != self._flat.size:

@@ -168,6 +168,16 @@ int edmp_sampler_set_graph(edmp_ctx* ctx, int on);
 int edmp_q_sample_dev(edmp_ctx* ctx, const double* x_dev, const double* eps_dev, const int32_t* t_host, int B, int C, int N,
                       int cumulative, int condition, double* xt_dev, double* mean_dev);
 
+/* ---- resident objects ----------------------------------------------------------------------------------- */
+/* The reference keeps Python objects alive side by side: one TemporalUNet per process, one IntersectionVolumeGuide per
+ * scene (infer_serial.py:50, 112).  A context holds up to 3 models and 8 guides (scene tables + row arrays) resident
+ * in HBM, addressed by a caller-chosen non-zero key; edmp_unet_load / edmp_scene_set / edmp_rows_set always act on the
+ * CURRENT slot.  edmp_*_slot(key) makes `key` current (parking the previous one, evicting the least recently used
+ * beyond the capacity) and returns 1 if the slot already holds a loaded object - nothing to upload -, 0 if it is
+ * empty (load into it next), < 0 on error.  Key 0 is the default slot of callers that never use slots. */
+int edmp_unet_slot(edmp_ctx* ctx, uint64_t key);
+int edmp_guide_slot(edmp_ctx* ctx, uint64_t key);
+
 /* ---- one logical batch over several GPUs ------------------------------------------------------------------ */
 /* The reference has no distributed code; its only coupling between batch rows is the whole-batch gradient norm
  * gradient1 / np.linalg.norm(gradient1) (lib/guide.py:629).  When one reference batch is row-sharded over ranks, the

@@ -89,3 +89,21 @@ def test_problem_file_round_trip(tmp_path):
     assert oc3[0, 3:7].tolist() == [0, 0, 0, 1] and oc3[1, 7:].tolist() == [0.07, 0.07, 0.4] and oc3[1, 3:7].tolist() == [0.5, 0.5, 0.5, 0.5]
     with pytest.raises(ValueError):
         scenes.problem_to_arrays({"cuboids": [], "start": s.tolist(), "goals": [g.tolist()]})
+
+
+def test_metrics_against_the_reference(golden):
+    """G13 (oracle/gen_golden_metrics.py): path length and SPARC of six trajectories computed by the UNMODIFIED
+    lib/metrics.py MetricsCalculator (end effector through the reference's 10-row DH chain, f32) and by the vendored
+    mpinets/third_party/sparc.py."""
+    g = golden("g13_metrics")
+    dt = float(g["dt"])
+    for i, tr in enumerate(g["trajectories"]):
+        ee = EV.end_effector_positions(tr)
+        assert np.abs(ee - g["ee_positions"][i]).max() <= 2e-6, i  # f64 here vs the reference's f32 chain
+        pl = EV.path_lengths(tr)
+        assert abs(pl["joint"] - g["joint_path_length"][i]) <= 1e-9 * max(1.0, g["joint_path_length"][i])
+        assert abs(pl["end_effector"] - g["ee_path_length"][i]) <= 2e-5 * max(1.0, g["ee_path_length"][i])
+        sj, se = EV.smoothness_metric(tr, dt)
+        assert abs(sj - g["joint_sparc"][i]) <= 1e-9 and abs(sj - g["third_party_joint_sparc"][i]) <= 1e-9, (i, sj, g["joint_sparc"][i])
+        assert abs(se - g["ee_sparc"][i]) <= 5e-4 * max(1.0, abs(g["ee_sparc"][i])), (i, se, g["ee_sparc"][i])  # f32 positions feed an FFT threshold
+    assert EV.smoothness_metric(g["trajectories"][4], dt) == (0.0, 0.0)  # constant trajectory: the reference returns 0

@@ -1035,3 +1035,72 @@ def test_best_trajectory_nan_semantics():
         _capi.check(lib.edmp_argmin_dev(ctx.h, ptr(v), len(vals), byref(out)))
         ctx.sync()
         assert out.value == want == int(torch.argmin(torch.tensor(vals)))
+
+
+def test_reference_written_checkpoint_on_the_gpu():
+    """G14: the checkpoint directory written by the reference's TemporalUNet.save() loads through
+    TemporalUNet(model_name=<dir>) exactly like the reference's load() (temporalunet.py:88-92) and the HIP forward
+    reproduces the reference's own output."""
+    import os
+
+    from edmp_amd.temporalunet import TemporalUNet
+
+    d = os.path.join(os.path.dirname(__file__), "golden", "g14_ref_checkpoint")
+    fw = np.load(os.path.join(d, "forward.npz"))
+    net = TemporalUNet(d, 7, 32, DEV, dims=tuple(int(v) for v in fw["dims"]), max_batch=4)
+    y = net(torch.tensor(fw["x"]), torch.tensor(fw["t"])).cpu().numpy()
+    assert np.abs(y - fw["y"]).max() <= 2e-5, np.abs(y - fw["y"]).max()
+
+
+def test_resident_slots_keep_alternating_objects_loaded(tiny_net):
+    """A context keeps several models and guides resident (edmp_unet_slot / edmp_guide_slot): alternating between two
+    TemporalUNets and between per-scene guides re-uploads nothing, and results are those of freshly bound objects."""
+    from edmp_amd import _capi, scenes
+    from edmp_amd import weights as W
+    from edmp_amd.guide import IntersectionVolumeGuide
+    from edmp_amd.runtime import get_context
+    from edmp_amd.temporalunet import TemporalUNet
+
+    ctx = get_context(DEV)
+    net_a, _ = tiny_net
+    net_b = TemporalUNet(None, 7, 32, DEV, dims=TINY_DIMS, state_dict=W.init_state_dict(6, 7, 32, TINY_DIMS), max_batch=8)
+    x = torch.randn(3, 7, 50, generator=torch.Generator().manual_seed(1))
+    t = torch.tensor([40.0])
+    ya, yb = net_a(x, t).cpu().numpy(), net_b(x, t).cpu().numpy()
+    assert not np.array_equal(ya, yb)
+    loads = []
+    orig = ctx.lib.edmp_unet_load
+
+    def counting(*a):
+        loads.append(1)
+        return orig(*a)
+
+    ctx.lib.edmp_unet_load = counting
+    try:
+        for _ in range(3):
+            assert np.array_equal(net_a(x, t).cpu().numpy(), ya) and np.array_equal(net_b(x, t).cpu().numpy(), yb)
+    finally:
+        ctx.lib.edmp_unet_load = orig
+    assert not loads, "alternating between two resident models must not re-upload weights"
+    cfgs = cfgs_for([1, 10], 2)
+    guides = [IntersectionVolumeGuide(scenes.random_scene(s, 5), DEV, cfgs, 4) for s in (1, 2, 3)]
+    q = torch.tensor(np.random.RandomState(0).uniform(-1, 1, (4, 7, 48)))
+    ref = [g.cost(q, 0).cpu().numpy() for g in guides]
+    sets = []
+    orig_s = ctx.lib.edmp_scene_set
+
+    def counting_s(*a):
+        sets.append(1)
+        return orig_s(*a)
+
+    ctx.lib.edmp_scene_set = counting_s
+    try:
+        for _ in range(2):
+            for g, r in zip(guides, ref):
+                assert np.array_equal(g.cost(q, 0).cpu().numpy(), r)
+    finally:
+        ctx.lib.edmp_scene_set = orig_s
+    assert not sets, "switching between resident per-scene guides must not rebuild the obstacle table"
+    # beyond the capacity (8 guides per context) the least recently used slot is evicted and transparently rebuilt
+    many = [IntersectionVolumeGuide(scenes.random_scene(10 + s, 3), DEV, cfgs, 4) for s in range(9)]
+    assert np.array_equal(guides[0].cost(q, 0).cpu().numpy(), ref[0]) and tuple(many[0].cost(q, 0).shape) == (4, 48, 9 * 3)

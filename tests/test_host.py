@@ -130,6 +130,26 @@ def test_checkpoint_format_round_trip(tmp_path):
     assert list(back) == list(sd) and all(np.array_equal(back[k], sd[k]) for k in sd)
 
 
+def test_checkpoint_written_by_the_reference():
+    """G14: weights_latest.pt produced by the reference's own TemporalUNet.save() (temporalunet.py:78-86) for a tiny
+    network (oracle/gen_golden_metrics.py): the reader returns every tensor of the state dict with the layout the
+    packer expects, and the oracle UNet reproduces the reference forward stored next to it."""
+    import torch
+
+    from edmp_amd import weights as W
+    from oracle import edmp_oracle as O
+
+    d = os.path.join(os.path.dirname(__file__), "golden", "g14_ref_checkpoint")
+    sd = W.load_checkpoint_dir(d)
+    fw = np.load(os.path.join(d, "forward.npz"))
+    dims = tuple(int(v) for v in fw["dims"])
+    assert W.infer_dims(sd) == (7, 32, dims)
+    shapes = W.unet_param_shapes(7, 32, dims)
+    assert list(sd) == list(shapes) and all(tuple(sd[k].shape) == tuple(shapes[k]) and sd[k].dtype == np.float32 for k in shapes)
+    y = O.UNetOracle(sd)(torch.tensor(fw["x"]), torch.tensor(fw["t"])).numpy()
+    assert np.abs(y - fw["y"]).max() <= 1e-6
+
+
 def test_franka_tables():
     from edmp_amd import franka
     from oracle import edmp_oracle as O
