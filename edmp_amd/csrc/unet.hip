@@ -196,6 +196,7 @@ struct UNet {
     edmp_unet_desc desc{};
     int max_batch = 0;
     float* wpack = nullptr;    // repacked conv weights + biases + gn affine
+    size_t wpack_floats = 0;
     float* tbias = nullptr;    // [T][tb_stride]
     int tb_stride = 0;
     std::vector<float*> bufs;  // activation buffers
@@ -1420,14 +1421,18 @@ static inline int round8(int c) { return (c + 7) / 8 * 8; }
 
 struct Packer {
     std::vector<float> host;
+    bool dry = false;   // layout only: offsets and sizes are computed, nothing is written (loading a packed image)
+    size_t total = 0;   // floats packed so far (== host.size() unless dry)
     size_t add(size_t n) {
-        size_t o = host.size();
-        host.resize(o + ((n + 3) / 4) * 4, 0.0f);  // keep every tensor 16-byte aligned
+        size_t o = total;
+        total += ((n + 3) / 4) * 4;  // keep every tensor 16-byte aligned
+        if (!dry) host.resize(total, 0.0f);
         return o;
     }
     // Conv1d weight (Cout, Cin, k) -> [tap][Cout][CinP]
     size_t conv(const float* w, int cout, int cin, int k, int cinp) {
         size_t o = add((size_t)k * cout * cinp);
+        if (dry) return o;
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
                 for (int t = 0; t < k; ++t) host[o + ((size_t)t * cout + co) * cinp + ci] = w[((size_t)co * cin + ci) * k + t];
@@ -1436,6 +1441,7 @@ struct Packer {
     // ConvTranspose1d weight (Cin, Cout, k) -> [tap][Cout][Cin]
     size_t convT(const float* w, int cin, int cout, int k) {
         size_t o = add((size_t)k * cout * cin);
+        if (dry) return o;
         for (int ci = 0; ci < cin; ++ci)
             for (int co = 0; co < cout; ++co)
                 for (int t = 0; t < k; ++t) host[o + ((size_t)t * cout + co) * cin + ci] = w[((size_t)ci * cout + co) * k + t];
@@ -1446,6 +1452,7 @@ struct Packer {
     size_t conv_frag(const float* w, const float* wres, int cout, int cin, int cinp, int L) {
         const int sw = wide_ms(cout);
         const int kt0 = (L == 2) ? 1 : 0, ntap = (L == 2) ? 3 : 5, nslab = ntap + (wres ? 1 : 0);
+        if (dry) return add((size_t)(cout / sw) * (cinp / (sw == 32 ? 8 : 16)) * nslab * 256);
         std::vector<float> tmp((size_t)6 * cout * cinp, 0.0f);
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci) {
@@ -1458,6 +1465,10 @@ struct Packer {
     }
     // strided Conv1d k3 (Cout, Cin, 3) or ConvTranspose1d k4 (Cin, Cout, 4) of a wide level -> fragment stream, slot = tap
     size_t resample_frag(const float* w, int cin, int cout, int k, bool transposed) {
+        if (dry) {
+            const int sw0 = wide_ms(cout);
+            return add((size_t)(cout / sw0) * (cin / (sw0 == 32 ? 8 : 16)) * k * 256);
+        }
         std::vector<float> tmp((size_t)6 * cout * cin, 0.0f);
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
@@ -1470,7 +1481,7 @@ struct Packer {
     }
     size_t vec(const float* v, int n) {
         size_t o = add(n);
-        memcpy(&host[o], v, sizeof(float) * n);
+        if (!dry) memcpy(&host[o], v, sizeof(float) * n);
         return o;
     }
 };
@@ -1512,8 +1523,14 @@ extern "C" int64_t edmp_unet_param_count(const edmp_unet_desc* desc) {
     return inventory(*desc).total;
 }
 
-extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* params, int64_t n_params, int max_batch) {
-    EDMP_REQUIRE(ctx && desc && params, "edmp_unet_load: null argument");
+// Layout id of the packed weight image: bump whenever the packing of any kernel family changes (a stale packed file then
+// fails to load instead of feeding a kernel the wrong fragment order)
+static const int kPackLayout = 201;
+
+// builds the layer program + device weight image.  packed == nullptr: repack `params` (state-dict order) on the host;
+// otherwise `packed` IS the device image (edmp_unet_read_packed of the same architecture): only the layout is computed
+static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* params, int64_t n_params, int max_batch, const float* packed,
+                      int64_t n_packed) {
     ctx->epoch++;
     EDMP_REQUIRE(desc->n_levels >= 2 && desc->n_levels <= EDMP_MAX_LEVELS, "n_levels out of range");
     EDMP_REQUIRE(desc->input_dim >= 1 && desc->input_dim <= 8, "input_dim must be in 1..8");
@@ -1521,6 +1538,12 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
     EDMP_REQUIRE(max_batch >= 1, "max_batch must be positive");
     for (int i = 0; i < desc->n_levels; ++i) EDMP_REQUIRE(desc->dims[i] % 8 == 0 && desc->dims[i] >= 8, "dims must be multiples of 8");
     RawNet inv = inventory(*desc);
+    std::vector<float> zeros;
+    if (packed) {  // the builder only reads `params` for data it writes; give its pointer arithmetic something valid
+        zeros.assign((size_t)inv.total, 0.0f);
+        params = zeros.data();
+        n_params = inv.total;
+    }
     EDMP_REQUIRE(inv.total == n_params, "parameter blob has %lld floats, architecture needs %lld", (long long)n_params, (long long)inv.total);
     EDMP_HIP_CHECK(hipSetDevice(ctx->device));
     if (ctx->unet) {
@@ -1538,6 +1561,7 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
     const int CP0 = 8;  // padded input channels
 
     Packer pk;
+    pk.dry = packed != nullptr;
     BufPool pool;
     // program is first built with buffer ids / weight offsets, resolved to pointers after allocation
     struct POp {
@@ -1854,12 +1878,18 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
     for (auto& o : pops)
         if (o.kind == OP_CONV || o.kind == OP_RCB || o.kind == OP_BLK || o.kind == OP_WRS) max_lc = std::max(max_lc, (size_t)o.Lout * o.Cout);
     u->buf_cap = max_lc * (size_t)max_batch;
-    if (hipMalloc((void**)&u->wpack, pk.host.size() * sizeof(float)) != hipSuccess) {
+    if (packed && (int64_t)pk.total != n_packed) {
         unet_destroy(u);
-        set_error("hipMalloc of %zu weight bytes failed", pk.host.size() * sizeof(float));
+        set_error("packed weight image has %lld floats, this architecture / library layout needs %zu", (long long)n_packed, pk.total);
+        return EDMP_ERR_ARG;
+    }
+    if (hipMalloc((void**)&u->wpack, pk.total * sizeof(float)) != hipSuccess) {
+        unet_destroy(u);
+        set_error("hipMalloc of %zu weight bytes failed", pk.total * sizeof(float));
         return EDMP_ERR_HIP;
     }
-    EDMP_HIP_CHECK(hipMemcpy(u->wpack, pk.host.data(), pk.host.size() * sizeof(float), hipMemcpyHostToDevice));
+    u->wpack_floats = pk.total;
+    EDMP_HIP_CHECK(hipMemcpy(u->wpack, packed ? packed : pk.host.data(), pk.total * sizeof(float), hipMemcpyHostToDevice));
     for (int i = 0; i < pool.n; ++i) {
         float* p = nullptr;
         if (hipMalloc((void**)&p, u->buf_cap * sizeof(float)) != hipSuccess) {
@@ -1989,6 +2019,31 @@ extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const f
     u->head_cin = dm[1];
     for (auto& t : tapr) u->taps.push_back({t.which, u->bufs[t.buf], t.C, t.L});
     ctx->unet = u;
+    return EDMP_OK;
+}
+
+extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* params, int64_t n_params, int max_batch) {
+    EDMP_REQUIRE(ctx && desc && params, "edmp_unet_load: null argument");
+    return unet_build(ctx, desc, params, n_params, max_batch, nullptr, 0);
+}
+
+extern "C" int edmp_unet_load_packed(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* packed, int64_t n_packed, int layout, int max_batch) {
+    EDMP_REQUIRE(ctx && desc && packed, "edmp_unet_load_packed: null argument");
+    EDMP_REQUIRE(layout == kPackLayout, "packed weight image has layout %d, this library packs layout %d: re-pack from the state dict", layout, kPackLayout);
+    return unet_build(ctx, desc, nullptr, 0, max_batch, packed, n_packed);
+}
+
+extern "C" int64_t edmp_unet_packed_size(edmp_ctx* ctx, int* layout) {
+    if (layout) *layout = kPackLayout;
+    return (ctx && ctx->unet) ? (int64_t)ctx->unet->wpack_floats : -1;
+}
+
+extern "C" int edmp_unet_read_packed(edmp_ctx* ctx, float* out_host, int64_t capacity) {
+    EDMP_REQUIRE(ctx && ctx->unet && out_host, "edmp_unet_read_packed: null argument / no model");
+    EDMP_REQUIRE(capacity >= (int64_t)ctx->unet->wpack_floats, "buffer of %lld floats, image has %zu", (long long)capacity, ctx->unet->wpack_floats);
+    EDMP_HIP_CHECK(hipSetDevice(ctx->device));
+    EDMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    EDMP_HIP_CHECK(hipMemcpy(out_host, ctx->unet->wpack, ctx->unet->wpack_floats * sizeof(float), hipMemcpyDeviceToHost));
     return EDMP_OK;
 }
 

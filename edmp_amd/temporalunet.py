@@ -26,13 +26,32 @@ class TemporalUNet:
     """
 
     def __init__(self, model_name, input_dim, time_dim, device, dims=(32, 64, 128, 256), *, state_dict=None, seed=0,
-                 max_batch=1024, horizon=50, T=255):
+                 max_batch=1024, horizon=50, T=255, use_packed=True):
         self.model_name = model_name
         self.input_dim, self.time_dim, self.dims = int(input_dim), int(time_dim), tuple(int(d) for d in dims)
         self.horizon, self.T = int(horizon), int(T)
         self.max_batch = int(max_batch)
         self.ctx = get_context(device)
         self.device = self.ctx.device
+        self._flat = None
+        self._packed = None
+        self._slot = new_slot_key()
+        if state_dict is None and model_name is not None and os.path.exists(model_name) and use_packed:
+            # fast path: the device image written by pack() - one mmap + one host-to-device copy instead of torch.load,
+            # 290 tensor copies and the host-side repack (used only if it matches this architecture, this library's
+            # packing layout, and is not older than the state-dict checkpoint)
+            pk = weights.read_packed(os.path.join(model_name, weights.PACKED_NAME))
+            ck = os.path.join(model_name, "weights_latest.pt")
+            layout = C.c_int()
+            self.ctx.lib.edmp_unet_packed_size(self.ctx.h, C.byref(layout))
+            if (pk is not None and pk["layout"] == layout.value and (pk["input_dim"], pk["time_dim"], pk["dims"], pk["horizon"], pk["T"]) ==
+                    (self.input_dim, self.time_dim, self.dims, self.horizon, self.T)
+                    and (not os.path.exists(ck) or os.path.getmtime(os.path.join(model_name, weights.PACKED_NAME)) >= os.path.getmtime(ck))):
+                self._packed = pk
+                self.losses = np.load(os.path.join(model_name, "losses.npy")) if os.path.exists(os.path.join(model_name, "losses.npy")) else np.array([])
+                print("Loaded Model at " + str(self.losses.size) + " epochs")
+                self._bind()
+                return
         if state_dict is None:
             if model_name is not None and os.path.exists(model_name):
                 state_dict = weights.load_checkpoint_dir(model_name)
@@ -43,6 +62,10 @@ class TemporalUNet:
                     os.mkdir(model_name)
                 self.losses = np.array([])
                 state_dict = weights.init_state_dict(seed, self.input_dim, self.time_dim, self.dims)
+        self._flat = self._flatten(state_dict)
+        self._bind()
+
+    def _flatten(self, state_dict):
         shapes = weights.unet_param_shapes(self.input_dim, self.time_dim, self.dims)
         missing = [k for k in shapes if k not in state_dict]
         if missing:
@@ -53,9 +76,7 @@ class TemporalUNet:
             if tuple(v.shape) != tuple(shp):
                 raise ValueError(f"{k}: shape {tuple(v.shape)} != expected {tuple(shp)}")
             flat.append(v.reshape(-1))
-        self._flat = np.ascontiguousarray(np.concatenate(flat))
-        self._slot = new_slot_key()
-        self._bind()
+        return np.ascontiguousarray(np.concatenate(flat))
 
     def _desc(self):
         d = _capi.UNetDesc()
@@ -78,10 +99,15 @@ class TemporalUNet:
             return
         ctx.bound_model = None
         d = self._desc()
-        n = ctx.lib.edmp_unet_param_count(C.byref(d))
-        if n != self._flat.size:
-            raise _capi.EdmpError(f"parameter count mismatch: python {self._flat.size}, library {n}")
-        _capi.check(ctx.lib.edmp_unet_load(ctx.h, C.byref(d), _capi.as_pf(self._flat), self._flat.size, self.max_batch), "edmp_unet_load")
+        if self._packed is not None:
+            blob = self._packed["blob"]
+            _capi.check(ctx.lib.edmp_unet_load_packed(ctx.h, C.byref(d), C.cast(blob.ctypes.data, _capi._pf), blob.size, self._packed["layout"], self.max_batch),
+                        "edmp_unet_load_packed")
+        else:
+            n = ctx.lib.edmp_unet_param_count(C.byref(d))
+            if n != self._flat.size:
+                raise _capi.EdmpError(f"parameter count mismatch: python {self._flat.size}, library {n}")
+            _capi.check(ctx.lib.edmp_unet_load(ctx.h, C.byref(d), _capi.as_pf(self._flat), self._flat.size, self.max_batch), "edmp_unet_load")
         ctx.bound_model = self
 
     def train(self, mode=True):
@@ -122,7 +148,25 @@ class TemporalUNet:
         _capi.check(self.ctx.lib.edmp_unet_flops(self.ctx.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def pack(self, path=None):
+        """Write the device weight image next to the checkpoint (<model_name>/weights_packed.edmp, or ``path``): later
+        constructions of this architecture load it with one mmap + one copy.  No reference counterpart."""
+        self._bind()
+        ctx = self.ctx
+        layout = C.c_int()
+        n = ctx.lib.edmp_unet_packed_size(ctx.h, C.byref(layout))
+        blob = np.empty(n, dtype=np.float32)
+        _capi.check(ctx.lib.edmp_unet_read_packed(ctx.h, _capi.as_pf(blob), n), "edmp_unet_read_packed")
+        if path is None:
+            if self.model_name is None:
+                raise ValueError("pack() needs a path for a model without a directory")
+            path = os.path.join(self.model_name, weights.PACKED_NAME)
+        weights.write_packed(path, layout.value, self.input_dim, self.time_dim, self.dims, self.horizon, self.T, blob)
+        return path
+
     def save(self):
+        if self._flat is None:  # constructed from a packed image: the state dict lives in the checkpoint next to it
+            self._flat = self._flatten(weights.load_checkpoint_dir(self.model_name))
         sd = {}
         off = 0
         for k, shp in weights.unet_param_shapes(self.input_dim, self.time_dim, self.dims).items():

@@ -116,3 +116,43 @@ def save_checkpoint_dir(model_name: str, sd) -> None:
     os.makedirs(model_name, exist_ok=True)
     torch.save(OrderedDict((k, torch.from_numpy(np.asarray(v))) for k, v in sd.items()), os.path.join(model_name, "weights_latest.pt"))
     np.save(os.path.join(model_name, "losses.npy"), np.array([]))
+
+
+# ---- packed weight image (edmp_unet_load_packed) --------------------------------------------------------------------
+PACKED_NAME = "weights_packed.edmp"
+_PACK_MAGIC = b"EDMPWPK1"
+_PACK_HEADER = 4096  # the float blob starts page-aligned so that it can be mmap'ed and handed to hipMemcpy as is
+
+
+def write_packed(path: str, layout: int, input_dim: int, time_dim: int, dims, horizon: int, T: int, blob: np.ndarray) -> None:
+    """``blob``: float32 device image returned by edmp_unet_read_packed."""
+    import struct
+
+    dims = tuple(int(d) for d in dims)
+    head = _PACK_MAGIC + struct.pack("<5i8i2iq", int(layout), int(input_dim), int(time_dim), len(dims), 0, *(dims + (0,) * (8 - len(dims))), int(horizon), int(T), int(blob.size))
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as f:
+        f.write(head.ljust(_PACK_HEADER, b"\0"))
+        f.write(np.ascontiguousarray(blob, dtype="<f4").tobytes())
+    os.replace(tmp, path)
+
+
+def read_packed(path: str):
+    """-> dict(layout, input_dim, time_dim, dims, horizon, T, blob (read-only float32 memmap)) or None if not a packed file."""
+    import struct
+
+    try:
+        with open(path, "rb") as f:
+            head = f.read(_PACK_HEADER)
+    except OSError:
+        return None
+    if len(head) < _PACK_HEADER or head[:8] != _PACK_MAGIC:
+        return None
+    vals = struct.unpack("<5i8i2iq", head[8 : 8 + struct.calcsize("<5i8i2iq")])
+    layout, input_dim, time_dim, n_levels, _ = vals[:5]
+    dims = tuple(vals[5 : 5 + n_levels])
+    horizon, T, n = vals[13], vals[14], vals[15]
+    if os.path.getsize(path) != _PACK_HEADER + 4 * n:
+        return None
+    blob = np.memmap(path, dtype="<f4", mode="r", offset=_PACK_HEADER, shape=(n,))
+    return dict(layout=layout, input_dim=input_dim, time_dim=time_dim, dims=dims, horizon=horizon, T=T, blob=blob)

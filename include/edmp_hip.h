@@ -60,6 +60,16 @@ typedef struct edmp_unet_desc {
 int64_t edmp_unet_param_count(const edmp_unet_desc* desc);
 /* upload + repack weights, precompute the (T x sum Cout) time-bias table, allocate activations for max_batch */
 int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* params, int64_t n_params, int max_batch);
+/* Packed weight image = the device-side layout edmp_unet_load produces from the state dict (conv weights as MFMA
+ * fragment streams / [tap][Cout][Cin], biases, GroupNorm affine, time-MLP weights), as ONE float blob that loads with a
+ * single host-to-device copy (e.g. straight from an mmap'ed file) instead of re-reading, flattening and repacking 120 MB
+ * (the reference's load is torch.load + load_state_dict, temporalunet.py:88-92).  edmp_unet_packed_size returns the
+ * image's float count of the current model and the library's layout id; an image only loads into the same
+ * architecture (desc) and layout id. */
+int64_t edmp_unet_packed_size(edmp_ctx* ctx, int* layout);
+int edmp_unet_read_packed(edmp_ctx* ctx, float* out_host, int64_t capacity);
+int edmp_unet_load_packed(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* packed, int64_t n_packed, int layout,
+                          int max_batch);
 /* replaces TemporalUNet.forward (temporalunet.py:47-76): x (B,C,N) f32, integer t in [1,T] -> eps (B,C,N) f32 */
 int edmp_unet_forward_dev(edmp_ctx* ctx, const float* x_dev, int B, int t, float* eps_dev);
 /* debug/parity: copy an internal activation, converted to the reference layout (B, C, L) f32.

@@ -1104,3 +1104,41 @@ def test_resident_slots_keep_alternating_objects_loaded(tiny_net):
     # beyond the capacity (8 guides per context) the least recently used slot is evicted and transparently rebuilt
     many = [IntersectionVolumeGuide(scenes.random_scene(10 + s, 3), DEV, cfgs, 4) for s in range(9)]
     assert np.array_equal(guides[0].cost(q, 0).cpu().numpy(), ref[0]) and tuple(many[0].cost(q, 0).shape) == (4, 48, 9 * 3)
+
+
+def test_packed_weight_image_round_trip(tmp_path):
+    """TemporalUNet.pack(): the device weight image written next to the checkpoint loads with one mmap + one copy and
+    gives bit-identical outputs; a stale image (older than the checkpoint, other architecture) is ignored."""
+    import os
+    import time as _time
+
+    from edmp_amd import weights as W
+    from edmp_amd.temporalunet import TemporalUNet
+
+    d = str(tmp_path / "TemporalUNetModel255_N50")
+    sd = W.init_state_dict(9, 7, 32, FULL_DIMS)
+    W.save_checkpoint_dir(d, sd)
+    x = torch.randn(5, 7, 50, generator=torch.Generator().manual_seed(2))
+    t = torch.tensor([31.0])
+    t0 = _time.perf_counter()
+    a = TemporalUNet(d, 7, 32, DEV, dims=FULL_DIMS, max_batch=8)
+    t_sd = _time.perf_counter() - t0
+    ya = a(x, t).cpu().numpy()
+    path = a.pack()
+    assert os.path.basename(path) == W.PACKED_NAME and os.path.getsize(path) > 80e6  # < 120 MB: taps that only ever meet zero padding (L = 2) are not stored
+    t0 = _time.perf_counter()
+    b = TemporalUNet(d, 7, 32, DEV, dims=FULL_DIMS, max_batch=8)
+    t_pk = _time.perf_counter() - t0
+    assert b._packed is not None and b._flat is None
+    assert np.array_equal(b(x, t).cpu().numpy(), ya)
+    print(f"load from state dict {t_sd:.2f} s, from the packed image {t_pk:.2f} s")
+    # another architecture in the same directory: the image is ignored, the state dict decides (and fails on shapes)
+    with pytest.raises((ValueError, KeyError)):
+        TemporalUNet(d, 7, 32, DEV, dims=TINY_DIMS, max_batch=8)
+    # a newer checkpoint invalidates the image
+    sd2 = W.init_state_dict(10, 7, 32, FULL_DIMS)
+    _time.sleep(1.1)
+    W.save_checkpoint_dir(d, sd2)
+    c = TemporalUNet(d, 7, 32, DEV, dims=FULL_DIMS, max_batch=8)
+    assert c._packed is None and not np.array_equal(c(x, t).cpu().numpy(), ya)
+    b.save()  # a model constructed from the image can still write the reference's state-dict format

@@ -150,6 +150,24 @@ def test_checkpoint_written_by_the_reference():
     assert np.abs(y - fw["y"]).max() <= 1e-6
 
 
+def test_packed_weight_file_format(tmp_path):
+    """weights_packed.edmp: page-aligned float blob behind a header naming the architecture and the packing layout;
+    truncated / foreign files are rejected (the loader then falls back to the state dict)."""
+    from edmp_amd import weights as W
+
+    blob = np.arange(1000, dtype=np.float32) * 0.5
+    p = str(tmp_path / W.PACKED_NAME)
+    W.write_packed(p, 201, 7, 32, (16, 16, 32), 50, 255, blob)
+    r = W.read_packed(p)
+    assert (r["layout"], r["input_dim"], r["time_dim"], r["dims"], r["horizon"], r["T"]) == (201, 7, 32, (16, 16, 32), 50, 255)
+    assert np.array_equal(np.asarray(r["blob"]), blob) and r["blob"].ctypes.data % 4096 == 0
+    with open(p, "r+b") as f:
+        f.truncate(4096 + 100)
+    assert W.read_packed(p) is None
+    (tmp_path / "x.bin").write_bytes(b"not a packed file" * 400)
+    assert W.read_packed(str(tmp_path / "x.bin")) is None and W.read_packed(str(tmp_path / "missing")) is None
+
+
 def test_franka_tables():
     from edmp_amd import franka
     from oracle import edmp_oracle as O
