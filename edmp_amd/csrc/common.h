@@ -122,6 +122,20 @@ __device__ __forceinline__ float dpp_xor_add(float x) {
     return x + __builtin_bit_cast(float, y);
 }
 
+// x + (x of lane ^ 16) resp. (lane ^ 32) with gfx950's v_permlane16_swap / v_permlane32_swap (VALU, a few cycles) instead of
+// a ds_bpermute round trip: swapping (x, x) leaves the even half-rows' value in one result register and the odd
+// half-rows' in the other, for every lane
+__device__ __forceinline__ float swap16_add(float x) {
+    const int xi = __builtin_bit_cast(int, x);
+    const auto r = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+    return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+}
+__device__ __forceinline__ float swap32_add(float x) {
+    const int xi = __builtin_bit_cast(int, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+    return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+}
+
 // x * tanh(softplus(x)) with torch's softplus threshold (20): blocks.py:27,65 -> torch.nn.Mish
 __device__ __forceinline__ float mish_f(float x) {
     float sp = (x > 20.0f) ? x : log1pf(expf(x));

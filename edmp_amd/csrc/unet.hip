@@ -175,13 +175,42 @@ struct BlkP {
     int B;
 };
 
-enum OpKind { OP_CONV = 0, OP_GN = 1, OP_RCB = 2, OP_BLK = 3, OP_WRS = 4 };  // OP_WRS: down/up-sampling conv of a wide level on wide_conv_kernel
+// whole-level kernel (level.hip)
+enum LevelMode { LV_DOWN = 0, LV_UP = 1, LV_UP_FINAL = 2 };
+
+struct LevelP {
+    const float* src1;  // [B][L][C1]
+    const float* src2;  // [B][L][C2] concatenated behind src1 on the channel axis, or nullptr
+    int C1, C2;
+    // weight fragment streams (pack_fragments, sw = 16: [C/16][K/16][slots][64][4])
+    const float* w11;   // RCB1 conv1, K = KX, slots 0..4 = taps, slot 5 = the residual 1x1 conv
+    const float* w12;   // RCB1 conv2, K = C
+    const float* w21;   // RCB2 conv1
+    const float* w22;   // RCB2 conv2
+    const float* wrs;   // resampling conv: k3 s2 (3 slots) | ConvTranspose k4 s2 (4 slots)
+    const float* wfin;  // final Conv1dBlock (LV_UP_FINAL)
+    // per-channel vectors [C]: conv bias, GroupNorm gamma / beta, time bias of step t, residual-conv bias
+    const float *b11, *g11, *be11, *tb1, *rb1;
+    const float *b12, *g12, *be12;
+    const float *b21, *g21, *be21, *tb2;
+    const float *b22, *g22, *be22;
+    const float* brs;
+    const float *bfin, *gfin, *befin;
+    float* skip_out;  // [B][L][C] output of the second block (the level's skip tensor), or nullptr
+    float* out;       // [B][LOUT][C] (LV_UP_FINAL: the final Conv1dBlock's output at the up-sampled length)
+    int B;
+};
+
+enum OpKind { OP_CONV = 0, OP_GN = 1, OP_RCB = 2, OP_BLK = 3, OP_WRS = 4, OP_LVL = 5 };  // OP_LVL: a whole 32/64-channel level (level.hip)  // OP_WRS: down/up-sampling conv of a wide level on wide_conv_kernel
 struct Op {
     OpKind kind;
     ConvP cv;
     GnP gn;
     RcbP rc;
     BlkP bk;      // OP_BLK: a whole residual block
+    LevelP lv;    // OP_LVL: a whole level
+    int lv_variant;
+    int lv_tb1, lv_tb2;  // offsets of the two blocks' time biases in the time-bias row
     int bk_variant;
     int rc_L;     // OP_RCB / OP_WRS: input positions
     int wrs_kind; // OP_WRS: WK_DOWN / WK_UP
@@ -443,6 +472,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
 
 }  // namespace edmp
 #include "wide.hip"
+#include "level.hip"
 namespace edmp {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1362,6 +1392,26 @@ static int launch_rcb(const RcbP& p, int L, hipStream_t s) {
     return EDMP_ERR_STATE;
 }
 
+// whole-level kernel variants (level.hip): (mode, channels, length, stored input channels) -> id, 0 = none
+static int level_variant(int mode, int C, int L, int c1, int c2) {
+    if (mode == LV_DOWN && C == 32 && L == 50 && c1 == 8 && c2 == 0) return 1;
+    if (mode == LV_DOWN && C == 64 && L == 25 && c1 == 32 && c2 == 0) return 2;
+    if (mode == LV_UP && C == 64 && L == 13 && c1 == 128 && c2 == 128) return 3;
+    if (mode == LV_UP_FINAL && C == 32 && L == 25 && c1 == 64 && c2 == 64) return 4;
+    return 0;
+}
+static int level_kx(int variant) { return variant == 1 ? 16 : variant == 2 ? 32 : variant == 3 ? 256 : 128; }
+static int launch_level(const LevelP& p, int variant, hipStream_t s) {
+    switch (variant) {
+        case 1: return launch_level_t<LV_DOWN, 32, 50, 4, 8>(p, s);
+        case 2: return launch_level_t<LV_DOWN, 64, 25, 4, 32>(p, s);
+        case 3: return launch_level_t<LV_UP, 64, 13, 4, 256>(p, s);
+        case 4: return launch_level_t<LV_UP_FINAL, 32, 25, 4, 128>(p, s);
+    }
+    set_error("no whole-level kernel variant %d", variant);
+    return EDMP_ERR_STATE;
+}
+
 // down/up-sampling convs of the wide levels (no GroupNorm behind them) on the position-tile kernel
 static bool wrs_supported(int cout, int cin, int Lin, bool transposed) {
     const int cg = cout / 8;
@@ -1399,6 +1449,10 @@ static void op_kernel_name(const Op& op, char* out) {
                  (op.kind == OP_RCB && op.rc.res_out) ? "true" : "false");
     }
     else if (op.kind == OP_BLK) snprintf(out, 64, "%s", blk_names[op.bk_variant]);
+    else if (op.kind == OP_LVL) {
+        static const char* lv_names[] = {"", "level_kernel<0, 32, 50, 4, 8>", "level_kernel<0, 64, 25, 4, 32>", "level_kernel<1, 64, 13, 4, 256>", "level_kernel<2, 32, 25, 4, 128>"};
+        snprintf(out, 64, "%s", lv_names[op.lv_variant]);
+    }
     else if (op.kind == OP_CONV) {
         const int kc = pick_kc(op.cv);
         if (op.cv.Cout % 64 == 0) snprintf(out, 64, "conv_mfma_kernel<64, 64, %d>", kc);
@@ -1525,7 +1579,7 @@ extern "C" int64_t edmp_unet_param_count(const edmp_unet_desc* desc) {
 
 // Layout id of the packed weight image: bump whenever the packing of any kernel family changes (a stale packed file then
 // fails to load instead of feeding a kernel the wrong fragment order)
-static const int kPackLayout = 201;
+static const int kPackLayout = 202;
 
 // builds the layer program + device weight image.  packed == nullptr: repack `params` (state-dict order) on the host;
 // otherwise `packed` IS the device image (edmp_unet_read_packed of the same architecture): only the layout is computed
@@ -1578,6 +1632,9 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
         size_t w2, b2, gamma2, beta2, wr, br;  // OP_BLK; br also = bias of a residual conv folded into an OP_RCB
         int blk;
         int res_out;  // OP_RCB: buffer receiving the folded residual 1x1 conv (-1: none)
+        // OP_LVL: offsets of the level's tensors in the packed image, in LevelP order; lv_skip: buffer of the skip output (-1: none)
+        size_t lvo[24];
+        int lv_variant, lv_tb1, lv_tb2, lv_skip;
         // fused conv+gn (OP_RCB): uses src1/src2/C1/C2/Lin/Cout/w/b/dst + gamma/beta/res/tb_off
     };
     std::vector<POp> pops;
@@ -1784,13 +1841,85 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
         return y2;
     };
 
+    // a whole level in one launch (level.hip): RCB, RCB, resampling conv (+ the final Conv1dBlock); consumes two entries
+    // of inv.rcbs like two emit_rcb calls would, in the same order (so the time-bias row keeps its layout)
+    auto emit_level = [&](int mode, int variant, TH xin, const TH* x2, const RawT& rs_w, const RawT& rs_b, bool want_skip, TH* skip_th) -> TH {
+        const RawRCB& r1 = inv.rcbs[rcb_idx++];
+        const RawRCB& r2 = inv.rcbs[rcb_idx++];
+        const int Cc = r1.cout, Ll = xin.L, KX = level_kx(variant);
+        const int cin_store = xin.C + (x2 ? x2->C : 0);
+        POp o{};
+        o.kind = OP_LVL;
+        o.lv_variant = variant;
+        o.src1 = xin.buf;
+        o.C1 = xin.C;
+        o.src2 = x2 ? x2->buf : -1;
+        o.C2 = x2 ? x2->C : 0;
+        o.Lin = Ll;
+        o.Cout = Cc;
+        size_t* q = o.lvo;
+        // LevelP order: w11 w12 w21 w22 wrs wfin | b11 g11 be11 rb1 | b12 g12 be12 | b21 g21 be21 | b22 g22 be22 | brs | bfin gfin befin
+        q[0] = pk.conv_frag(params + r1.cb[0].w.off, params + r1.rw.off, Cc, r1.cin, KX, Ll);
+        q[1] = pk.conv_frag(params + r1.cb[1].w.off, nullptr, Cc, Cc, Cc, Ll);
+        q[2] = pk.conv_frag(params + r2.cb[0].w.off, nullptr, Cc, Cc, Cc, Ll);
+        q[3] = pk.conv_frag(params + r2.cb[1].w.off, nullptr, Cc, Cc, Cc, Ll);
+        q[4] = pk.resample_frag(params + rs_w.off, Cc, Cc, mode == LV_DOWN ? 3 : 4, mode != LV_DOWN);
+        q[5] = (mode == LV_UP_FINAL) ? pk.conv_frag(params + inv.final_cb.w.off, nullptr, Cc, Cc, Cc, 50) : 0;
+        q[6] = pk.vec(params + r1.cb[0].b.off, Cc), q[7] = pk.vec(params + r1.cb[0].gw.off, Cc), q[8] = pk.vec(params + r1.cb[0].gb.off, Cc);
+        q[9] = pk.vec(params + r1.rb.off, Cc);
+        q[10] = pk.vec(params + r1.cb[1].b.off, Cc), q[11] = pk.vec(params + r1.cb[1].gw.off, Cc), q[12] = pk.vec(params + r1.cb[1].gb.off, Cc);
+        q[13] = pk.vec(params + r2.cb[0].b.off, Cc), q[14] = pk.vec(params + r2.cb[0].gw.off, Cc), q[15] = pk.vec(params + r2.cb[0].gb.off, Cc);
+        q[16] = pk.vec(params + r2.cb[1].b.off, Cc), q[17] = pk.vec(params + r2.cb[1].gw.off, Cc), q[18] = pk.vec(params + r2.cb[1].gb.off, Cc);
+        q[19] = pk.vec(params + rs_b.off, Cc);
+        if (mode == LV_UP_FINAL) {
+            q[20] = pk.vec(params + inv.final_cb.b.off, Cc), q[21] = pk.vec(params + inv.final_cb.gw.off, Cc), q[22] = pk.vec(params + inv.final_cb.gb.off, Cc);
+        }
+        for (const RawRCB* r : {&r1, &r2}) {  // time-bias table columns, block order
+            (r == &r1 ? o.lv_tb1 : o.lv_tb2) = tb_cursor;
+            tb_cursor += Cc;
+            tw_all.insert(tw_all.end(), params + r->tw.off, params + r->tw.off + (size_t)Cc * td);
+            tb_all.insert(tb_all.end(), params + r->tb.off, params + r->tb.off + Cc);
+        }
+        o.lv_skip = -1;
+        if (want_skip) {
+            o.lv_skip = pool.get();
+            *skip_th = TH{o.lv_skip, Cc, Ll};
+        }
+        int Lout = (mode == LV_DOWN) ? (Ll - 1) / 2 + 1 : 2 * Ll;
+        if (mode != LV_DOWN && (Lout == 8 || Lout == 14 || Lout == 26)) Lout -= 1;
+        o.Lout = Lout;
+        o.dst = pool.get();
+        const double vp = (double)valid_pairs(Ll, Ll, 5, 1, 2, false);
+        const int k = mode == LV_DOWN ? 3 : 4;
+        o.fn = 2.0 * Ll * Cc * 5.0 * ((double)r1.cin + 3.0 * Cc) + 2.0 * Ll * Cc * (double)r1.cin +
+               (mode == LV_DOWN ? 2.0 * Lout * Cc * (double)Cc * k : 2.0 * Ll * (double)Cc * Cc * k) + (mode == LV_UP_FINAL ? 2.0 * Lout * Cc * (double)Cc * 5 : 0.0);
+        o.fe = 2.0 * vp * Cc * ((double)cin_store + 3.0 * Cc) + 2.0 * Ll * Cc * (double)cin_store +
+               2.0 * (double)valid_pairs(Ll, Lout, k, 2, 1, mode != LV_DOWN) * Cc * (double)Cc +
+               (mode == LV_UP_FINAL ? 2.0 * (double)valid_pairs(Lout, Lout, 5, 1, 2, false) * Cc * (double)Cc : 0.0);
+        pops.push_back(o);
+        return TH{o.dst, Cc, Lout};
+    };
+    const bool use_level = use_fused && getenv("EDMP_NO_LEVEL") == nullptr && getenv("EDMP_NO_BLOCK") == nullptr && !use_side;
+
     TH x{pool.get(), CP0, N};
     const int x_in_buf = x.buf;
     pool.pin(x_in_buf);  // written by the sampler kernels between forwards: never recycled as an activation
     std::vector<TH> skips;
+    bool final_fused = false;
     struct TapRec { int which; int buf, C, L; };
     std::vector<TapRec> tapr;
     for (int i = 0; i < nd; ++i) {
+        if (const int lvv = (use_level && i != nd - 1) ? level_variant(LV_DOWN, dm[i + 1], x.L, x.C, 0) : 0) {
+            // the skip of level 0 is never consumed (5 up-samplers for 6 skips, temporalunet.py:31-32,66-67): not even written
+            TH sk{-1, dm[i + 1], x.L};
+            TH xo = emit_level(LV_DOWN, lvv, x, nullptr, inv.down_w[i], inv.down_b[i], i > 0, &sk);
+            pool.put(x.buf);
+            skips.push_back(sk);
+            x = xo;
+            tapr.push_back({i, x.buf, x.C, x.L});
+            pool.pin(x.buf);
+            continue;
+        }
         TH a = emit_rcb(x, nullptr);
         pool.put(x.buf);  // the block input is dead once both consumers (conv1, residual) are emitted
         TH b = emit_rcb(a, nullptr);
@@ -1826,6 +1955,24 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
         TH sk = skips.back();
         skips.pop_back();
         EDMP_REQUIRE(sk.L == x.L && sk.C == x.C, "skip/upsample shape mismatch at up level %d (L %d vs %d)", j, sk.L, x.L);
+        EDMP_REQUIRE(sk.buf >= 0, "up level %d consumes a skip tensor that the fused down level did not write", j);
+        {
+            const bool last = (i == 2);
+            const int mode = (last && dm[1] == dm[i - 1] && 2 * x.L == N) ? LV_UP_FINAL : LV_UP;
+            if (const int lvv = use_level ? level_variant(mode, dm[i - 1], x.L, x.C, sk.C) : 0) {
+                TH xo = emit_level(mode, lvv, x, &sk, inv.up_w[j], inv.up_b[j], false, nullptr);
+                pool.put(x.buf);
+                pool.put(sk.buf);
+                x = xo;
+                if (mode == LV_UP_FINAL) {
+                    final_fused = true;  // the level kernel already applied final_conv.0
+                } else {
+                    tapr.push_back({200 + j, x.buf, x.C, x.L});
+                    pool.pin(x.buf);
+                }
+                continue;
+            }
+        }
         TH a = emit_rcb(x, &sk);
         pool.put(x.buf);
         pool.put(sk.buf);
@@ -1848,7 +1995,7 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
     }
     EDMP_REQUIRE(x.L == N, "decoder output length %d != horizon %d", x.L, N);
     // final Conv1dBlock + 1x1 head
-    {
+    if (!final_fused) {
         size_t w = pk.conv(params + inv.final_cb.w.off, dm[1], dm[1], 5, dm[1]);
         size_t b = pk.vec(params + inv.final_cb.b.off, dm[1]);
         size_t g = pk.vec(params + inv.final_cb.gw.off, dm[1]), be = pk.vec(params + inv.final_cb.gb.off, dm[1]);
@@ -1876,7 +2023,7 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
     // allocate
     size_t max_lc = (size_t)N * CP0;
     for (auto& o : pops)
-        if (o.kind == OP_CONV || o.kind == OP_RCB || o.kind == OP_BLK || o.kind == OP_WRS) max_lc = std::max(max_lc, (size_t)o.Lout * o.Cout);
+        if (o.kind == OP_CONV || o.kind == OP_RCB || o.kind == OP_BLK || o.kind == OP_WRS || o.kind == OP_LVL) max_lc = std::max(max_lc, (size_t)std::max(o.Lout, o.Lin) * o.Cout);
     u->buf_cap = max_lc * (size_t)max_batch;
     if (packed && (int64_t)pk.total != n_packed) {
         unet_destroy(u);
@@ -1953,6 +2100,30 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
             c.dst = u->bufs[o.dst];
             op.bk_variant = o.blk;
             op.tb_off = o.tb_off;
+            op.flops_nominal = o.fn;
+            op.flops_exec = o.fe;
+            u->flops_nominal += o.fn;
+            u->flops_exec += o.fe;
+        } else if (o.kind == OP_LVL) {
+            LevelP& c = op.lv;
+            const float* W0 = u->wpack;
+            c.src1 = u->bufs[o.src1];
+            c.src2 = o.src2 >= 0 ? u->bufs[o.src2] : nullptr;
+            c.C1 = o.C1;
+            c.C2 = o.C2;
+            c.w11 = W0 + o.lvo[0], c.w12 = W0 + o.lvo[1], c.w21 = W0 + o.lvo[2], c.w22 = W0 + o.lvo[3], c.wrs = W0 + o.lvo[4], c.wfin = W0 + o.lvo[5];
+            c.b11 = W0 + o.lvo[6], c.g11 = W0 + o.lvo[7], c.be11 = W0 + o.lvo[8], c.rb1 = W0 + o.lvo[9];
+            c.b12 = W0 + o.lvo[10], c.g12 = W0 + o.lvo[11], c.be12 = W0 + o.lvo[12];
+            c.b21 = W0 + o.lvo[13], c.g21 = W0 + o.lvo[14], c.be21 = W0 + o.lvo[15];
+            c.b22 = W0 + o.lvo[16], c.g22 = W0 + o.lvo[17], c.be22 = W0 + o.lvo[18];
+            c.brs = W0 + o.lvo[19];
+            c.bfin = W0 + o.lvo[20], c.gfin = W0 + o.lvo[21], c.befin = W0 + o.lvo[22];
+            c.tb1 = c.tb2 = nullptr;
+            c.skip_out = o.lv_skip >= 0 ? u->bufs[o.lv_skip] : nullptr;
+            c.out = u->bufs[o.dst];
+            op.lv_variant = o.lv_variant;
+            op.lv_tb1 = o.lv_tb1;
+            op.lv_tb2 = o.lv_tb2;
             op.flops_nominal = o.fn;
             op.flops_exec = o.fe;
             u->flops_nominal += o.fn;
@@ -2106,6 +2277,12 @@ int unet_run_program(edmp_ctx* ctx, int B, int t) {
             p.add_tb = op.tb_off >= 0 ? trow + op.tb_off : nullptr;
             EDMP_REQUIRE(!(p.add_tb && p.add_res), "fused conv block: a launch adds the time bias (conv1) or the residual (conv2), not both");
             rc = op.rc_rows ? launch_rows(p, op.rc_rows, s) : launch_rcb(p, op.rc_L, s);
+        } else if (op.kind == OP_LVL) {
+            LevelP p = op.lv;
+            p.B = B;
+            p.tb1 = trow + op.lv_tb1;
+            p.tb2 = trow + op.lv_tb2;
+            rc = launch_level(p, op.lv_variant, s);
         } else if (op.kind == OP_WRS) {
             RcbP p = op.rc;
             p.B = B;

@@ -85,8 +85,16 @@ def test_unet_golden(golden, tag, dims):
                 a = net.activation(i, x.shape[0]).cpu().numpy()
                 assert maxabs(a, g[f"trace_down{i}"]) <= 5e-4, f"down{i}"
             assert maxabs(net.activation(100, x.shape[0]).cpu().numpy(), g["trace_mid"]) <= 5e-4
+            from edmp_amd import _capi
+
             for j in range(n_lv - 1):
-                a = net.activation(200 + j, x.shape[0]).cpu().numpy()
+                try:
+                    a = net.activation(200 + j, x.shape[0]).cpu().numpy()
+                except _capi.EdmpError:
+                    # the last up level of the full-size net is one launch together with final_conv.0 (level.hip): its
+                    # up-sampled activation never exists in HBM; eps above covers it
+                    assert j == n_lv - 2 and tag == "full"
+                    continue
                 assert maxabs(a, g[f"trace_up{j}"]) <= 5e-4, f"up{j}"
 
 
@@ -122,7 +130,7 @@ def test_full_unet_fused_kernels_vs_oracle_ragged(oracle):
         for i in range(6):
             assert maxabs(net.activation(i, B).cpu().numpy(), tr[f"down{i}"].numpy()) <= 5e-4, (B, f"down{i}")
         assert maxabs(net.activation(100, B).cpu().numpy(), tr["mid"].numpy()) <= 5e-4
-        for j in range(5):
+        for j in range(4):  # up4's activation stays on chip: that level runs as one launch with final_conv.0 (level.hip); eps covers it
             assert maxabs(net.activation(200 + j, B).cpu().numpy(), tr[f"up{j}"].numpy()) <= 5e-4, (B, f"up{j}")
 
 
