@@ -1294,6 +1294,12 @@ static int launch_gn(const GnP& p, hipStream_t s) {
 // position-tile kernel (wide.hip) instances: channels per GroupNorm group cg = Cout/8 and the input length select
 // the tile height MS (32 samples for cg >= 32, 16 for the 128-channel levels)
 static int wide_ms(int cout) { return cout / 8 >= 32 ? 32 : 16; }
+// the L = 2 convolutions of the 512-channel levels in Karatsuba form (3 instead of 4 matrix products; wide.hip WK_K5K2);
+// EDMP_NO_KARATSUBA=1 selects the direct form (A/B runs)
+static bool karatsuba_l2() {
+    static const bool on = getenv("EDMP_NO_KARATSUBA") == nullptr;
+    return on;
+}
 static bool rcb_supported(int cout, int L, int c1, int c2) {
     const int cg = cout / 8;
     const bool shape = (cg == 64 && (L == 2 || L == 4)) || (cg == 32 && (L == 4 || L == 7)) || (cg == 16 && (L == 7 || L == 13));
@@ -1381,7 +1387,10 @@ static int launch_rcb(const RcbP& p, int L, hipStream_t s) {
     const bool res = p.res_out != nullptr;
 #define EDMP_K5(MS, CG, GS, LL) \
     return res ? launch_wide_t<WK_K5, MS, CG, GS, LL, true>(p, s) : launch_wide_t<WK_K5, MS, CG, GS, LL, false>(p, s);
-    if (cg == 64 && L == 2) { EDMP_K5(32, 64, 64, 2) }
+    if (cg == 64 && L == 2) {
+        if (karatsuba_l2()) return res ? launch_wide_t<WK_K5K2, 32, 64, 64, 2, true>(p, s) : launch_wide_t<WK_K5K2, 32, 64, 64, 2, false>(p, s);
+        EDMP_K5(32, 64, 64, 2)
+    }
     if (cg == 64 && L == 4) { EDMP_K5(32, 64, 64, 4) }
     if (cg == 32 && L == 4) { EDMP_K5(32, 32, 32, 4) }
     if (cg == 32 && L == 7) { EDMP_K5(32, 32, 32, 7) }
@@ -1445,7 +1454,8 @@ static void op_kernel_name(const Op& op, char* out) {
     if (op.kind == OP_RCB && op.rc_rows) snprintf(out, 64, "%s", rows_names[op.rc_rows]);
     else if (op.kind == OP_RCB || op.kind == OP_WRS) {
         const int cg = op.rc.Cout / 8, ms = wide_ms(op.rc.Cout);
-        snprintf(out, 64, "wide_conv_kernel<%d, %d, %d, %d, %d, %s>", op.kind == OP_RCB ? 0 : op.wrs_kind, ms, cg < 32 ? 32 : cg, cg, op.rc_L,
+        const int kind = op.kind == OP_RCB ? ((cg == 64 && op.rc_L == 2 && karatsuba_l2()) ? 3 : 0) : op.wrs_kind;
+        snprintf(out, 64, "wide_conv_kernel<%d, %d, %d, %d, %d, %s>", kind, ms, cg < 32 ? 32 : cg, cg, op.rc_L,
                  (op.kind == OP_RCB && op.rc.res_out) ? "true" : "false");
     }
     else if (op.kind == OP_BLK) snprintf(out, 64, "%s", blk_names[op.bk_variant]);
@@ -1514,7 +1524,8 @@ struct Packer {
                 if (wres) tmp[((size_t)5 * cout + co) * cinp + ci] = wres[(size_t)co * cin + ci];
             }
         size_t o = add((size_t)(cout / sw) * (cinp / (sw == 32 ? 8 : 16)) * nslab * 256);
-        pack_fragments(tmp.data(), cout, cinp, kt0, ntap, wres != nullptr, &host[o], sw);
+        if (L == 2 && sw == 32 && cout / 8 == 64 && karatsuba_l2()) pack_fragments_k2(tmp.data(), cout, cinp, wres != nullptr, &host[o]);
+        else pack_fragments(tmp.data(), cout, cinp, kt0, ntap, wres != nullptr, &host[o], sw);
         return o;
     }
     // strided Conv1d k3 (Cout, Cin, 3) or ConvTranspose1d k4 (Cin, Cout, 4) of a wide level -> fragment stream, slot = tap
@@ -1579,7 +1590,7 @@ extern "C" int64_t edmp_unet_param_count(const edmp_unet_desc* desc) {
 
 // Layout id of the packed weight image: bump whenever the packing of any kernel family changes (a stale packed file then
 // fails to load instead of feeding a kernel the wrong fragment order)
-static const int kPackLayout = 202;
+static const int kPackLayout = 203;
 
 // builds the layer program + device weight image.  packed == nullptr: repack `params` (state-dict order) on the host;
 // otherwise `packed` IS the device image (edmp_unet_read_packed of the same architecture): only the layout is computed
@@ -1736,7 +1747,9 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
         o.res_out = -1;
         o.dst = pool.get();
         o.fn = 2.0 * a.L * cout * (double)cin_true * 5;
-        o.fe = 2.0 * (double)valid_pairs(a.L, a.L, 5, 1, 2, false) * cout * (double)(o.C1 + o.C2);
+        // executed = issued MFMA work: the L = 2 Karatsuba form runs 3 matrix products where the direct form runs 4
+        const bool k2 = a.L == 2 && cout / 8 == 64 && karatsuba_l2() && rcb_supported(cout, a.L, o.C1, o.C2);
+        o.fe = 2.0 * (k2 ? 3.0 : (double)valid_pairs(a.L, a.L, 5, 1, 2, false)) * cout * (double)(o.C1 + o.C2);
         pops.push_back(o);
         return TH{o.dst, cout, a.L};
     };

@@ -49,49 +49,62 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-enum WideKind { WK_K5 = 0, WK_DOWN = 1, WK_UP = 2 };
+// WK_K5K2: the Conv1dBlock at L = 2 in Karatsuba form.  With two positions the k5 conv is the 2x2 Toeplitz product
+//     y0 = w2 x0 + w3 x1,  y1 = w1 x0 + w2 x1   (taps 0 and 4 only ever meet zero padding)
+// = four (Cin x Cout) matrix products per sample block.  Three suffice: P = w2 (x0 + x1), Q = (w3 - w2) x1,
+// R = (w1 - w2) x0, y0 = P + Q, y1 = P + R: the weight differences are formed once at load, x0 + x1 when the chunk is
+// staged into LDS, P / Q / R accumulate in three tiles and are combined when the epilogue reads them back - 25 % fewer
+// MFMAs on the twelve L = 2 convolutions of every forward, exact in exact arithmetic (fp32 rounding of the sums aside).
+enum WideKind { WK_K5 = 0, WK_DOWN = 1, WK_UP = 2, WK_K5K2 = 3 };
 
 // MS: samples per workgroup = MFMA tile height (32 or 16); CG: output channels per workgroup; GS: channels per GroupNorm
 // group (WK_K5; CG % GS == 0); LIN: input positions; RES: fold the block's residual 1x1 conv (WK_K5)
 template <int KIND, int MS, int CG, int GS, int LIN, bool RES>
 struct WideCfg {
     static constexpr int NW = 4;                     // waves per workgroup
-    static constexpr int L = LIN;                    // input positions (all staged per chunk)
-    static constexpr int LOUT = (KIND == WK_K5) ? LIN : (KIND == WK_DOWN) ? (LIN - 1) / 2 + 1 : ((2 * LIN == 8 || 2 * LIN == 14 || 2 * LIN == 26) ? 2 * LIN - 1 : 2 * LIN);
-    static constexpr bool GN = (KIND == WK_K5);      // GroupNorm + Mish + add epilogue (else: + bias)
+    static constexpr bool K2 = (KIND == WK_K5K2);
+    static constexpr int LLOAD = LIN;                // input positions fetched from HBM per chunk
+    static constexpr int L = K2 ? 3 : LIN;           // positions staged in LDS (K2: x0, x1, x0 + x1)
+    static constexpr int LOUT = (KIND == WK_K5 || K2) ? LIN : (KIND == WK_DOWN) ? (LIN - 1) / 2 + 1 : ((2 * LIN == 8 || 2 * LIN == 14 || 2 * LIN == 26) ? 2 * LIN - 1 : 2 * LIN);
+    static constexpr int LACC = K2 ? 3 : LOUT;       // accumulator tiles per slab (K2: P, Q, R)
+    static constexpr bool GN = (KIND == WK_K5 || K2);  // GroupNorm + Mish + add epilogue (else: + bias)
     static constexpr int SW = MS;                    // output channels per slab (MFMA tile width = height)
     static constexpr int KG = (MS == 32) ? 8 : 16;   // channels per K group = four MFMAs (K = 2 resp. 4 each)
     static constexpr int AR = (MS == 32) ? 16 : 4;   // accumulator registers per tile
     static constexpr int S = CG / SW;                // output slabs per workgroup
     static constexpr int KSPLIT = NW / S;            // waves sharing a slab, each with its own K slice
-    static constexpr int KC = (KG * KSPLIT > 32) ? KG * KSPLIT : 32;  // channels per staged chunk
+    // channels per staged chunk = one barrier (64-channel chunks were measured neutral for the Karatsuba form: -2 % K loop, +1 k cycles of prologue)
+    static constexpr int KC = (KG * KSPLIT > 32) ? KG * KSPLIT : 32;
     static constexpr int QW = KC / KG / KSPLIT;      // K groups per wave per chunk
     static constexpr int LDK = KC + 4;
     static constexpr int KT0 = (KIND == WK_K5 && LIN == 2) ? 1 : 0;  // first tap that can be valid
-    static constexpr int NTAP = (KIND == WK_K5) ? ((LIN == 2) ? 3 : 5) : (KIND == WK_DOWN) ? 3 : 4;  // taps that can be valid
+    static constexpr int NTAP = K2 ? 3 : (KIND == WK_K5) ? ((LIN == 2) ? 3 : 5) : (KIND == WK_DOWN) ? 3 : 4;  // weight slots per K group
     static constexpr int NSLAB = NTAP + (RES ? 1 : 0);
     // weight slot of the pair (output tile l, input position lp), -1 if the tap does not exist
     static constexpr int slot(int l, int lp) {
+        if (K2) return (l == 0 && lp == 2) ? 0 : (l == 1 && lp == 1) ? 1 : (l == 2 && lp == 0) ? 2 : -1;  // P, Q, R
         const int t = (KIND == WK_K5) ? lp - l + 2 - KT0 : (KIND == WK_DOWN) ? lp - 2 * l + 1 : l + 1 - 2 * lp;
         return (t >= 0 && t < NTAP) ? t : -1;
     }
     static constexpr int A_FL = L * MS * LDK;        // floats per activation stage
     static constexpr int NTH = NW * 64;
-    static constexpr int A_F4 = L * MS * (KC / 4);   // float4 items per stage
+    static constexpr int A_F4 = LLOAD * MS * (KC / 4);  // float4 items fetched per chunk
     static constexpr int NA = (A_F4 + NTH - 1) / NTH;
+    static constexpr int NPER = MS * (KC / 4) / NTH;    // staging items of a thread per position (K2)
+    static constexpr int NCOMMIT = NA + (K2 ? NPER : 0);  // ds_writes per thread per chunk (K2: + the sum position)
     static constexpr int NBL = QW * NSLAB;           // weight-fragment loads per wave per chunk
-    static constexpr int YS = LOUT * CG + 4;
+    static constexpr int YS = LACC * CG + 4;
     static constexpr int NP = KSPLIT;                // partial tiles per output element
     static constexpr int PPR = NTH / MS;             // threads per sample row in the final pass
     static constexpr int ROW_F4 = LOUT * CG / 4;     // float4 per sample row
     static constexpr int NF4 = (ROW_F4 + PPR - 1) / PPR;
     // MFMA blocks: one per (K group q, input position lp) = all tiles fed by that A fragment (+ the residual tile)
     static constexpr int NBLK = QW * L;
-    static constexpr int NSIDE = NA + NBL + NA;      // side work items of a step: activation loads, weight loads, commits
+    static constexpr int NSIDE = NA + NBL + NCOMMIT;  // side work items of a step: activation loads, weight loads, commits
     static constexpr int pairs() {
         int n = 0;
         for (int lp = 0; lp < L; ++lp)
-            for (int l = 0; l < LOUT; ++l)
+            for (int l = 0; l < LACC; ++l)
                 if (slot(l, lp) >= 0) ++n;
         return n;
     }
@@ -104,7 +117,8 @@ struct WideCfg {
     static_assert(MS == 32 || MS == 16, "tile height 32 (32x32x2 MFMA) or 16 (16x16x4 MFMA)");
     static_assert(NBLK >= 3 && 4 * (NBLK - 1) >= 1, "the memory work of a step is spread over the blocks before the last");
     static_assert(CG % SW == 0 && NW % S == 0 && S <= NW, "slabs per workgroup must divide the wave count");
-    static_assert(!RES || KIND == WK_K5, "the folded residual 1x1 conv belongs to a Conv1dBlock");
+    static_assert(!RES || KIND == WK_K5 || K2, "the folded residual 1x1 conv belongs to a Conv1dBlock");
+    static_assert(!K2 || (LIN == 2 && (MS * (KC / 4)) % NTH == 0), "Karatsuba form: two positions; a thread's staging items k and k + NPER are the two positions of one (row, channel quad)");
     static_assert((LOUT * CG) % 4 == 0, "whole float4 columns");
     static_assert(!GN || CG % GS == 0, "whole GroupNorm groups per workgroup");
     static_assert(!GN || GS == CG || (4 * PPR) % CG == 0, "a thread's columns of the final pass lie in one GroupNorm group");
@@ -124,7 +138,9 @@ template <int KIND, int MS, int CG, int GS, int LIN, bool RES>
 __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
     using Cf = WideCfg<KIND, MS, CG, GS, LIN, RES>;
     using acc_t = typename WideAcc<MS>::type;
-    constexpr int L = Cf::L, LOUT = Cf::LOUT, SW = Cf::SW, KG = Cf::KG, AR = Cf::AR;
+    constexpr int L = Cf::L, LLOAD = Cf::LLOAD, LOUT = Cf::LOUT, LACC = Cf::LACC, SW = Cf::SW, KG = Cf::KG, AR = Cf::AR;
+    constexpr bool K2 = Cf::K2;
+    constexpr int NCOMMIT = Cf::NCOMMIT;
     constexpr int S = Cf::S, KC = Cf::KC, QW = Cf::QW, LDK = Cf::LDK, NTAP = Cf::NTAP, NSLAB = Cf::NSLAB;
     constexpr int A_FL = Cf::A_FL, NTH = Cf::NTH, A_F4 = Cf::A_F4, NA = Cf::NA, YS = Cf::YS, NP = Cf::NP;
     constexpr int NBLK = Cf::NBLK, NSIDE = Cf::NSIDE, NBL = Cf::NBL;
@@ -149,22 +165,22 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
         const int lp = e / (MS * (KC / 4)), rem = e % (MS * (KC / 4));
         const int row = rem / (KC / 4), c4 = (rem % (KC / 4)) * 4;
         const int sb = min(b0 + row, p.B - 1);
-        a_g1[k] = (sb * L + lp) * p.C1 + c4;
-        a_g2[k] = (sb * L + lp) * p.C2 + c4;
+        a_g1[k] = (sb * LLOAD + lp) * p.C1 + c4;
+        a_g2[k] = (sb * LLOAD + lp) * p.C2 + c4;
         a_l[k] = lp * (MS * LDK) + row * LDK + c4;
     }
     // ---- weight fragment stream of this wave
     const float* wb = p.W + ((size_t)(blockIdx.x * S + s) * NKG) * (NSLAB * 256) + lane * 4;
 
-    acc_t acc[LOUT];
-    acc_t racc[RES ? L : 1];
+    acc_t acc[LACC];
+    acc_t racc[RES ? LLOAD : 1];
 #pragma unroll
-    for (int t = 0; t < LOUT; ++t)
+    for (int t = 0; t < LACC; ++t)
 #pragma unroll
         for (int i = 0; i < AR; ++i) acc[t][i] = 0.0f;
     if constexpr (RES) {
 #pragma unroll
-        for (int t = 0; t < L; ++t)
+        for (int t = 0; t < LLOAD; ++t)
 #pragma unroll
             for (int i = 0; i < AR; ++i) racc[t][i] = 0.0f;
     }
@@ -187,6 +203,10 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
 #pragma unroll
         for (int k = 0; k < NA; ++k)
             if ((A_F4 % NTH == 0) || tid + k * NTH < A_F4) *reinterpret_cast<f32x4*>(st + a_l[k]) = r[k];
+        if constexpr (K2) {  // position 2 = x0 + x1
+#pragma unroll
+            for (int j = 0; j < Cf::NPER; ++j) *reinterpret_cast<f32x4*>(st + a_l[j] + 2 * (MS * LDK)) = r[j] + r[j + Cf::NPER];
+        }
     };
     auto load_b = [&](int nc, float4(&b)[QW][NSLAB]) __attribute__((always_inline)) {
         const float* w = wb + ((size_t)(nc * (KC / KG) + ks * QW)) * (NSLAB * 256);
@@ -234,21 +254,26 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
         auto side = [&](auto xc) __attribute__((always_inline)) {
             constexpr int X = decltype(xc)::value;  // slot index
             constexpr int NSLOT = 4 * (NBLK - 1);
-            constexpr int NX = FIRST ? NA : 0;       // extra loads / commits of the first step
-            constexpr int NITEM = NSIDE + 2 * NX;
+            constexpr int NX = FIRST ? NA : 0;       // extra loads of the first step
+            constexpr int NXC = FIRST ? NCOMMIT : 0;  // ... and its extra commits
+            constexpr int NITEM = NA + NBL + NCOMMIT + NX + NXC;
+            // commit item k of a staged chunk: k < NA the fetched positions, k == NA (Karatsuba form) position 2 = x0 + x1
+            auto commit_item = [&](auto kc, float* stp, const f32x4(&r)[NA]) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k < NA) {
+                    if ((A_F4 % NTH == 0) || tid + k * NTH < A_F4) *reinterpret_cast<f32x4*>(stp + a_l[k]) = r[k];
+                } else {
+                    *reinterpret_cast<f32x4*>(stp + a_l[k - NA] + 2 * (MS * LDK)) = r[k - NA] + r[k - NA + Cf::NPER];
+                }
+            };
             static_for<0, NITEM>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
                 if constexpr (j * NSLOT / NITEM == X) {
                     if constexpr (j < NX) r1[j] = *reinterpret_cast<const f32x4*>(src1c + (first1 ? a_g1[j] : a_g2[j]) + ci1);
                     else if constexpr (j < NX + NA) ra[j - NX] = *reinterpret_cast<const f32x4*>(src + (first ? a_g1[j - NX] : a_g2[j - NX]) + ci0);
                     else if constexpr (j < NX + NA + NBL) bn[(j - NX - NA) / NSLAB][(j - NX - NA) % NSLAB] = *reinterpret_cast<const float4*>(w + (j - NX - NA) * 256);
-                    else if constexpr (j < 2 * NX + NA + NBL) {
-                        constexpr int k = j - NX - NA - NBL;
-                        if ((A_F4 % NTH == 0) || tid + k * NTH < A_F4) *reinterpret_cast<f32x4*>(stn + a_l[k]) = r1[k];
-                    } else {
-                        constexpr int k = j - 2 * NX - NA - NBL;
-                        if ((A_F4 % NTH == 0) || tid + k * NTH < A_F4) *reinterpret_cast<f32x4*>(stw + a_l[k]) = ra[k];
-                    }
+                    else if constexpr (j < NX + NA + NBL + NXC) commit_item(std::integral_constant<int, j - NX - NA - NBL>{}, stn, r1);
+                    else commit_item(std::integral_constant<int, j - NX - NA - NBL - NXC>{}, stw, ra);
                 }
             });
         };
@@ -267,11 +292,11 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
                 // different accumulators (the 16x16x4 MFMA has 40 cycles of dependent latency for 32 of issue); after
                 // each round one slot of memory work rides in the shadow of the round's last MFMA
 #define EDMP_W_COMP(J, R)                                                                                                   \
-    static_for<0, LOUT>([&](auto lc) __attribute__((always_inline)) {                                                     \
+    static_for<0, LACC>([&](auto lc) __attribute__((always_inline)) {                                                     \
         constexpr int l = decltype(lc)::value;                                                                              \
         if constexpr (Cf::slot(l, lp) >= 0) { EDMP_W_MFMA(acc[l], bc[q][Cf::slot(l, lp) >= 0 ? Cf::slot(l, lp) : 0], J) }   \
     });                                                                                                                     \
-    if constexpr (RES) { EDMP_W_MFMA(racc[lp], bc[q][NTAP], J) }                                                            \
+    if constexpr (RES && lp < LLOAD) { EDMP_W_MFMA(racc[lp < LLOAD ? lp : 0], bc[q][NTAP], J) }                             \
     __builtin_amdgcn_sched_barrier(0);                                                                                      \
     if constexpr (X < NBLK - 1) {                                                                                           \
         side(std::integral_constant<int, 4 * X + R>{});                                                                     \
@@ -335,7 +360,7 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
     auto acc_row = [&](int r) __attribute__((always_inline)) { return (MS == 32) ? (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) : 4 * (lane >> 4) + r; };
     if constexpr (RES) {
 #pragma unroll
-        for (int l = 0; l < L; ++l)
+        for (int l = 0; l < LLOAD; ++l)
 #pragma unroll
             for (int r = 0; r < AR; ++r) Yw[acc_row(r) * YS + l * CG] = racc[l][r] + rbias_v;
         __syncthreads();
@@ -352,16 +377,16 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
                         const float4 pv = *reinterpret_cast<const float4*>(Y + q * (MS * YS) + erow * YS + col);
                         rv.x += pv.x, rv.y += pv.y, rv.z += pv.z, rv.w += pv.w;
                     }
-                    *reinterpret_cast<float4*>(p.res_out + ((size_t)(b0 + erow) * L + l) * p.Cout + ch) = rv;
+                    *reinterpret_cast<float4*>(p.res_out + ((size_t)(b0 + erow) * LLOAD + l) * p.Cout + ch) = rv;
                 }
             }
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int l = 0; l < LOUT; ++l)
+    for (int l = 0; l < LACC; ++l)
 #pragma unroll
-        for (int r = 0; r < AR; ++r) Yw[acc_row(r) * YS + l * CG] = acc[l][r] + bias_v;
+        for (int r = 0; r < AR; ++r) Yw[acc_row(r) * YS + l * CG] = acc[l][r] + ((K2 && l > 0) ? 0.0f : bias_v);  // K2: the bias rides in P
     __syncthreads();
     EDMP_STAMP(0, 3)
     {
@@ -373,11 +398,22 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
             const int f = epart + PPR * i;
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((ROW_F4 % PPR == 0) || f < ROW_F4) {
-                v[i] = *reinterpret_cast<const float4*>(Y + erow * YS + 4 * f);
+                if constexpr (K2) {
+                    // output position l of channel quad c: y0 = P + Q, y1 = P + R (tiles 0 | 1 | 2 of the partial buffers)
+                    const int col = 4 * f, l = col / CG, c = col % CG;
 #pragma unroll
-                for (int q = 1; q < NP; ++q) {
-                    const float4 pv = *reinterpret_cast<const float4*>(Y + q * (MS * YS) + erow * YS + 4 * f);
-                    v[i].x += pv.x, v[i].y += pv.y, v[i].z += pv.z, v[i].w += pv.w;
+                    for (int q = 0; q < NP; ++q) {
+                        const float4 pp = *reinterpret_cast<const float4*>(Y + q * (MS * YS) + erow * YS + c);
+                        const float4 pq = *reinterpret_cast<const float4*>(Y + q * (MS * YS) + erow * YS + (1 + l) * CG + c);
+                        v[i].x += pp.x + pq.x, v[i].y += pp.y + pq.y, v[i].z += pp.z + pq.z, v[i].w += pp.w + pq.w;
+                    }
+                } else {
+                    v[i] = *reinterpret_cast<const float4*>(Y + erow * YS + 4 * f);
+#pragma unroll
+                    for (int q = 1; q < NP; ++q) {
+                        const float4 pv = *reinterpret_cast<const float4*>(Y + q * (MS * YS) + erow * YS + 4 * f);
+                        v[i].x += pv.x, v[i].y += pv.y, v[i].z += pv.z, v[i].w += pv.w;
+                    }
                 }
                 sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
             }
@@ -455,6 +491,21 @@ inline void pack_fragments(const float* w_tco_ci, int cout, int cin, int kt0, in
                     for (int j = 0; j < 4; ++j) o[lane * 4 + j] = src[j];
                 }
             }
+}
+
+// Karatsuba form of the L = 2 Conv1dBlock (WK_K5K2): [tap][Cout][Cin] taps 1..3 (+ residual at tap index 5) ->
+// slot 0 = w2, slot 1 = w3 - w2, slot 2 = w1 - w2 (+ the residual slab), then the fragment stream of pack_fragments
+inline void pack_fragments_k2(const float* w_tco_ci, int cout, int cin, bool res, float* out) {
+    std::vector<float> t((size_t)6 * cout * cin, 0.0f);
+    const size_t n = (size_t)cout * cin;
+    for (size_t i = 0; i < n; ++i) {
+        const float w1 = w_tco_ci[1 * n + i], w2 = w_tco_ci[2 * n + i], w3 = w_tco_ci[3 * n + i];
+        t[0 * n + i] = w2;
+        t[1 * n + i] = w3 - w2;
+        t[2 * n + i] = w1 - w2;
+        if (res) t[5 * n + i] = w_tco_ci[5 * n + i];
+    }
+    pack_fragments(t.data(), cout, cin, 0, 3, res, out, 32);
 }
 
 template <int KIND, int MS, int CG, int GS, int LIN, bool RES>

@@ -57,7 +57,7 @@ static float time_us(F&& f, int iters) {
 // Conv1dBlock (k5 + GroupNorm + Mish + add [+ folded residual 1x1 conv]): round-1 kernel(s) vs the position-tile kernel.
 // MS = 32: reference = legacy rcb_conv_kernel; MS = 16 (128-channel levels): reference = rcb_rows_kernel (+ conv_mfma for the
 // residual 1x1 conv, which round 1 ran as its own launch)
-template <int MS, int CG, int GS, int L, bool RES>
+template <int MS, int CG, int GS, int L, bool RES, int KIND = WK_K5>
 static void run_wide(int B, int C1, int C2, bool with_res_add) {
     const int Cout = GS * 8, Cin = C1 + C2;
     const int ntap_store = 6;
@@ -67,9 +67,10 @@ static void run_wide(int B, int C1, int C2, bool with_res_add) {
     auto hx2 = rnd((size_t)B * L * std::max(C2, 1), 3, 1.5f);
     auto hb = rnd(Cout, 4, 0.1f), hg = rnd(Cout, 5, 1.0f), hbe = rnd(Cout, 6, 0.3f), htb = rnd(Cout, 7, 0.5f), hrb = rnd(Cout, 8, 0.1f);
     auto hres = rnd((size_t)B * L * Cout, 9, 1.0f);
-    using Cf = WideCfg<WK_K5, MS, CG, GS, L, RES>;
+    using Cf = WideCfg<KIND, MS, CG, GS, L, RES>;
     std::vector<float> hWf((size_t)(Cout / Cf::SW) * (Cin / Cf::KG) * Cf::NSLAB * 256);
-    pack_fragments(hW.data(), Cout, Cin, Cf::KT0, Cf::NTAP, RES, hWf.data(), Cf::SW);
+    if constexpr (KIND == WK_K5K2) pack_fragments_k2(hW.data(), Cout, Cin, RES, hWf.data());
+    else pack_fragments(hW.data(), Cout, Cin, Cf::KT0, Cf::NTAP, RES, hWf.data(), Cf::SW);
     float *W = up(hW), *Wf = up(hWf), *x1 = up(hx1), *x2 = up(hx2), *bias = up(hb), *gam = up(hg), *bet = up(hbe), *tb = up(htb), *rb = up(hrb), *res = up(hres);
     float *d_old, *d_new, *r_old, *r_new;
     const size_t nout = (size_t)B * L * Cout;
@@ -122,7 +123,7 @@ static void run_wide(int B, int C1, int C2, bool with_res_add) {
             if (RES) launch_conv(c, 0);
         }
     };
-    auto f_new = [&] { launch_wide_t<WK_K5, MS, CG, GS, L, RES>(pn, 0); };
+    auto f_new = [&] { launch_wide_t<KIND, MS, CG, GS, L, RES>(pn, 0); };
     f_old();
     f_new();
     hipError_t e = hipDeviceSynchronize();
@@ -139,7 +140,7 @@ static void run_wide(int B, int C1, int C2, bool with_res_add) {
         t_new = std::min(t_new, time_us(f_new, 50));
     }
     const double fl = 2.0 * B * (double)Cout * Cin * (Cf::valid_pairs() + (RES ? L : 0));
-    printf("k5<MS%d,cg%2d,L%2d,res%d> Cin=%4d+%4d  max|d| %.2e (ref %.1f) res %.2e | old %7.2f us %6.1f TF | new %7.2f us %6.1f TF (%.3f of 157.3) | x%.3f\n", MS, GS, L,
+    printf("k5%s<MS%d,cg%2d,L%2d,res%d> Cin=%4d+%4d  max|d| %.2e (ref %.1f) res %.2e | old %7.2f us %6.1f TF | new %7.2f us %6.1f TF (%.3f of 157.3) | x%.3f\n", KIND == WK_K5K2 ? "-karatsuba" : "", MS, GS, L,
            (int)RES, C1, C2, d1, rm, d2, t_old, fl / t_old / 1e6, t_new, fl / t_new / 1e6, fl / t_new / 1e6 / 157.3, t_old / t_new);
 #ifdef EDMP_STAMPS
     {
@@ -331,6 +332,8 @@ int main(int argc, char** argv) {
     // >= 256 channels (32-sample tiles, 32x32x2 MFMA)
     run_wide<32, 64, 64, 2, false>(B, 512, 0, true);
     run_wide<32, 64, 64, 2, true>(B, 512, 512, false);
+    run_wide<32, 64, 64, 2, false, WK_K5K2>(B, 512, 0, true);
+    run_wide<32, 64, 64, 2, true, WK_K5K2>(B, 512, 512, false);
     run_wide<32, 64, 64, 4, false>(B, 512, 0, false);
     run_wide<32, 64, 64, 4, true>(B, 256, 0, false);
     run_wide<32, 32, 32, 4, false>(B, 256, 0, true);
