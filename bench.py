@@ -181,7 +181,8 @@ def main():
             },
             "best": {"rank": best["rank"], "row": best["index"], "swept_volume": best["volume"], "geometric_success_proxy": best["success"],
                      "note": "random-init denoiser: the proxy (zero t=0 swept AABB volume + joint limits) is expected to be false; reported, never gated"},
-            "unet_flops_per_traj_step": {"nominal": nominal, "executed_after_tap_skipping": executed, "survey": SURVEY_FLOPS_PER_TRAJ_STEP},
+            "unet_flops_per_traj_step": {"nominal": nominal, "direct_form_after_tap_skipping": net.flops_direct_form(), "issued_mfma": executed, "survey": SURVEY_FLOPS_PER_TRAJ_STEP,
+                                         "note": "issued < direct form: the L=2 / L=4 Conv1dBlocks run in Karatsuba form (3 of 4 resp. 9 of 14 matrix products)"},
         }
 
     # ---- informative: whole-scene wall time when the noise is NOT pre-resident (never `value`) -------------------------
@@ -245,7 +246,9 @@ def main():
             tf = r["flop"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
             rows.append({"kernel": name, "launches": r["launches"], "avg_us": 1e3 * r["ms"] / r["launches"], "share": r["ms"] / conv_ms if conv_ms else 0.0,
                          "executed_tflops": tf, "frac": tf / PEAK_F32_MFMA_TFLOPS})
+        conv_direct = net.flops_direct_form() - head
         ach = conv_exec * B * T / (conv_ms * 1e-3) / 1e12
+        ach_direct = conv_direct * B * T / (conv_ms * 1e-3) / 1e12
         tb = traffic_bytes_per_launch(pmc_traffic())
         avg_s = 1e-3 * conv_ms / max(launches, 1)
         out["roofline"] = {
@@ -256,7 +259,10 @@ def main():
             "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s",
             "frac": ach / PEAK_F32_MFMA_TFLOPS,
-            "flops": "executed (padding taps never issued)",
+            "flops": "MFMA work actually issued (padding taps never issued; Karatsuba forms at L=2/L=4 issue 3 of 4 / 9 of 14 products): matrix-pipe utilisation",
+            # the same time against the direct form's FLOPs with padding taps skipped - the figure round 1's review computed (0.53 there)
+            "achieved_direct_form": ach_direct,
+            "frac_direct_form": ach_direct / PEAK_F32_MFMA_TFLOPS,
             "traffic": tb,  # HBM bytes per conv launch (PMC FETCH_SIZE x2 + WRITE_SIZE passes, committed under profiles/)
             "traffic_detail": pmc_traffic(),
             # north-star asks for the HBM fraction too: PMC bytes per launch / average launch duration vs 8 TB/s
@@ -264,7 +270,7 @@ def main():
             "achieved_nominal": conv_nominal * B * T / (conv_ms * 1e-3) / 1e12,
             "launches": launches,
             "avg_launch_us": 1e3 * conv_ms / max(launches, 1),
-            "flops_per_launch_executed": conv_exec * B * T / max(launches, 1),
+            "flops_per_launch_issued": conv_exec * B * T / max(launches, 1),
             "conv_ms_per_call": conv_ms,
             "conv_share_of_step": conv_ms / ms_step,
             "timing": {"ms_per_step_timed": ms_step, "passA_program_brackets_conv_ms": conv_ms, "passA_wall_ms": passA_wall_ms, "passB_per_launch_brackets_ms": ev_ms,

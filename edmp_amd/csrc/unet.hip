@@ -217,7 +217,8 @@ struct Op {
     int rc_rows;  // OP_RCB: 0 = rcb_conv_kernel (wide levels), else rcb_rows_kernel variant
     int tb_off;   // GN: offset into the time-bias row, -1 if none
     int branch;   // 0 = main stream; 1 = fork point (record before this op); 2 = runs on the side stream; 3 = join (wait) before this op
-    double flops_nominal, flops_exec;  // per trajectory
+    double flops_nominal, flops_exec;  // per trajectory: every tap | MFMA work actually issued (padding taps skipped, Karatsuba forms)
+    double flops_direct;               // per trajectory: the direct form with padding taps skipped (round-1 'executed' accounting)
     char name[64];                     // kernel instance as rocprofv3 prints it (without the edmp:: prefix)
 };
 
@@ -239,7 +240,7 @@ struct UNet {
     // taps of intermediate activations for parity (buffer, C, L); valid right after a forward
     struct Tap { int which; const float* p; int C, L; };
     std::vector<Tap> taps;
-    double flops_nominal = 0, flops_exec = 0;
+    double flops_nominal = 0, flops_exec = 0, flops_direct = 0;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1300,6 +1301,11 @@ static bool karatsuba_l2() {
     static const bool on = getenv("EDMP_NO_KARATSUBA") == nullptr;
     return on;
 }
+// ... and the L = 4 convolutions of the 256/512-channel levels in the nested form (9 instead of 14 products; WK_K5K4)
+static bool karatsuba_l4() {
+    static const bool on = getenv("EDMP_NO_KARATSUBA") == nullptr && getenv("EDMP_NO_KARATSUBA4") == nullptr;
+    return on;
+}
 static bool rcb_supported(int cout, int L, int c1, int c2) {
     const int cg = cout / 8;
     const bool shape = (cg == 64 && (L == 2 || L == 4)) || (cg == 32 && (L == 4 || L == 7)) || (cg == 16 && (L == 7 || L == 13));
@@ -1391,8 +1397,14 @@ static int launch_rcb(const RcbP& p, int L, hipStream_t s) {
         if (karatsuba_l2()) return res ? launch_wide_t<WK_K5K2, 32, 64, 64, 2, true>(p, s) : launch_wide_t<WK_K5K2, 32, 64, 64, 2, false>(p, s);
         EDMP_K5(32, 64, 64, 2)
     }
-    if (cg == 64 && L == 4) { EDMP_K5(32, 64, 64, 4) }
-    if (cg == 32 && L == 4) { EDMP_K5(32, 32, 32, 4) }
+    if (cg == 64 && L == 4) {
+        if (karatsuba_l4()) return res ? launch_wide_t<WK_K5K4, 32, 64, 64, 4, true>(p, s) : launch_wide_t<WK_K5K4, 32, 64, 64, 4, false>(p, s);
+        EDMP_K5(32, 64, 64, 4)
+    }
+    if (cg == 32 && L == 4) {
+        if (karatsuba_l4()) return res ? launch_wide_t<WK_K5K4, 32, 32, 32, 4, true>(p, s) : launch_wide_t<WK_K5K4, 32, 32, 32, 4, false>(p, s);
+        EDMP_K5(32, 32, 32, 4)
+    }
     if (cg == 32 && L == 7) { EDMP_K5(32, 32, 32, 7) }
     if (cg == 16 && L == 7) { EDMP_K5(16, 32, 16, 7) }
     if (cg == 16 && L == 13) { EDMP_K5(16, 32, 16, 13) }
@@ -1454,7 +1466,7 @@ static void op_kernel_name(const Op& op, char* out) {
     if (op.kind == OP_RCB && op.rc_rows) snprintf(out, 64, "%s", rows_names[op.rc_rows]);
     else if (op.kind == OP_RCB || op.kind == OP_WRS) {
         const int cg = op.rc.Cout / 8, ms = wide_ms(op.rc.Cout);
-        const int kind = op.kind == OP_RCB ? ((cg == 64 && op.rc_L == 2 && karatsuba_l2()) ? 3 : 0) : op.wrs_kind;
+        const int kind = op.kind == OP_RCB ? ((cg == 64 && op.rc_L == 2 && karatsuba_l2()) ? 3 : (cg >= 32 && op.rc_L == 4 && karatsuba_l4()) ? 4 : 0) : op.wrs_kind;
         snprintf(out, 64, "wide_conv_kernel<%d, %d, %d, %d, %d, %s>", kind, ms, cg < 32 ? 32 : cg, cg, op.rc_L,
                  (op.kind == OP_RCB && op.rc.res_out) ? "true" : "false");
     }
@@ -1516,7 +1528,7 @@ struct Packer {
     size_t conv_frag(const float* w, const float* wres, int cout, int cin, int cinp, int L) {
         const int sw = wide_ms(cout);
         const int kt0 = (L == 2) ? 1 : 0, ntap = (L == 2) ? 3 : 5, nslab = ntap + (wres ? 1 : 0);
-        if (dry) return add((size_t)(cout / sw) * (cinp / (sw == 32 ? 8 : 16)) * nslab * 256);
+        if (dry) return add((size_t)(cout / sw) * (cinp / (sw == 32 ? 8 : 16)) * ((L == 4 && sw == 32 && karatsuba_l4()) ? 9 + (wres ? 1 : 0) : nslab) * 256);
         std::vector<float> tmp((size_t)6 * cout * cinp, 0.0f);
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci) {
@@ -1524,7 +1536,13 @@ struct Packer {
                 if (wres) tmp[((size_t)5 * cout + co) * cinp + ci] = wres[(size_t)co * cin + ci];
             }
         size_t o = add((size_t)(cout / sw) * (cinp / (sw == 32 ? 8 : 16)) * nslab * 256);
-        if (L == 2 && sw == 32 && cout / 8 == 64 && karatsuba_l2()) pack_fragments_k2(tmp.data(), cout, cinp, wres != nullptr, &host[o]);
+        if (L == 4 && sw == 32 && karatsuba_l4()) {
+            // nine slots (+ residual) instead of five: the stream is longer than `o` was sized for - re-reserve
+            total = o;
+            if (!dry) host.resize(total);
+            o = add((size_t)(cout / 32) * (cinp / 8) * (9 + (wres ? 1 : 0)) * 256);
+            pack_fragments_k4(tmp.data(), cout, cinp, wres != nullptr, &host[o]);
+        } else if (L == 2 && sw == 32 && cout / 8 == 64 && karatsuba_l2()) pack_fragments_k2(tmp.data(), cout, cinp, wres != nullptr, &host[o]);
         else pack_fragments(tmp.data(), cout, cinp, kt0, ntap, wres != nullptr, &host[o], sw);
         return o;
     }
@@ -1590,7 +1608,7 @@ extern "C" int64_t edmp_unet_param_count(const edmp_unet_desc* desc) {
 
 // Layout id of the packed weight image: bump whenever the packing of any kernel family changes (a stale packed file then
 // fails to load instead of feeding a kernel the wrong fragment order)
-static const int kPackLayout = 203;
+static const int kPackLayout = 204;
 
 // builds the layer program + device weight image.  packed == nullptr: repack `params` (state-dict order) on the host;
 // otherwise `packed` IS the device image (edmp_unet_read_packed of the same architecture): only the layout is computed
@@ -1638,7 +1656,7 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
         int y, L, C, res;
         size_t gamma, beta;
         int tb_off;
-        double fn, fe;
+        double fn, fe, fd;  // FLOPs per trajectory: nominal | issued | direct form without padding taps (0: same as fe)
         int branch;
         size_t w2, b2, gamma2, beta2, wr, br;  // OP_BLK; br also = bias of a residual conv folded into an OP_RCB
         int blk;
@@ -1749,7 +1767,9 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
         o.fn = 2.0 * a.L * cout * (double)cin_true * 5;
         // executed = issued MFMA work: the L = 2 Karatsuba form runs 3 matrix products where the direct form runs 4
         const bool k2 = a.L == 2 && cout / 8 == 64 && karatsuba_l2() && rcb_supported(cout, a.L, o.C1, o.C2);
-        o.fe = 2.0 * (k2 ? 3.0 : (double)valid_pairs(a.L, a.L, 5, 1, 2, false)) * cout * (double)(o.C1 + o.C2);
+        const bool k4 = a.L == 4 && cout / 8 >= 32 && karatsuba_l4() && rcb_supported(cout, a.L, o.C1, o.C2);
+        o.fe = 2.0 * (k2 ? 3.0 : k4 ? 9.0 : (double)valid_pairs(a.L, a.L, 5, 1, 2, false)) * cout * (double)(o.C1 + o.C2);
+        o.fd = 2.0 * (double)valid_pairs(a.L, a.L, 5, 1, 2, false) * cout * (double)(o.C1 + o.C2);
         pops.push_back(o);
         return TH{o.dst, cout, a.L};
     };
@@ -1818,6 +1838,7 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
                 c1.br = pk.vec(params + r.rb.off, r.cout);
                 c1.fn += 2.0 * x.L * r.cout * (double)r.cin;
                 c1.fe += 2.0 * x.L * r.cout * (double)cin_store;
+                c1.fd += 2.0 * x.L * r.cout * (double)cin_store;
                 rr_buf = c1.res_out;
                 res_buf = c1.res_out;
             } else if (r.has_res) {
@@ -2093,6 +2114,8 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
             op.flops_exec = o.fe;
             u->flops_nominal += o.fn;
             u->flops_exec += o.fe;
+            op.flops_direct = o.fd > 0 ? o.fd : o.fe;
+            u->flops_direct += op.flops_direct;
         } else if (o.kind == OP_BLK) {
             BlkP& c = op.bk;
             c.src1 = u->bufs[o.src1];
@@ -2117,6 +2140,8 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
             op.flops_exec = o.fe;
             u->flops_nominal += o.fn;
             u->flops_exec += o.fe;
+            op.flops_direct = o.fd > 0 ? o.fd : o.fe;
+            u->flops_direct += op.flops_direct;
         } else if (o.kind == OP_LVL) {
             LevelP& c = op.lv;
             const float* W0 = u->wpack;
@@ -2141,6 +2166,8 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
             op.flops_exec = o.fe;
             u->flops_nominal += o.fn;
             u->flops_exec += o.fe;
+            op.flops_direct = o.fd > 0 ? o.fd : o.fe;
+            u->flops_direct += op.flops_direct;
         } else if (o.kind == OP_WRS) {
             RcbP& c = op.rc;
             c.src1 = u->bufs[o.src1];
@@ -2157,6 +2184,8 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
             op.flops_exec = o.fe;
             u->flops_nominal += o.fn;
             u->flops_exec += o.fe;
+            op.flops_direct = o.fd > 0 ? o.fd : o.fe;
+            u->flops_direct += op.flops_direct;
         } else if (o.kind == OP_RCB) {
             RcbP& c = op.rc;
             c.src1 = u->bufs[o.src1];
@@ -2180,6 +2209,8 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
             op.flops_exec = o.fe;
             u->flops_nominal += o.fn;
             u->flops_exec += o.fe;
+            op.flops_direct = o.fd > 0 ? o.fd : o.fe;
+            u->flops_direct += op.flops_direct;
         } else {
             GnP& g = op.gn;
             g.y = u->bufs[o.y];
@@ -2196,6 +2227,7 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
     }
     u->flops_nominal += head_flops;
     u->flops_exec += head_flops;
+    u->flops_direct += head_flops;
     u->x_in = u->bufs[x_in_buf];
     u->h_last = u->bufs[x.buf];
     u->head_w = u->wpack + hw;
@@ -2389,6 +2421,12 @@ extern "C" int edmp_unet_read_activation_dev(edmp_ctx* ctx, int which, int B, fl
         }
     set_error("no activation tap %d", which);
     return EDMP_ERR_ARG;
+}
+
+extern "C" int edmp_unet_flops_direct(edmp_ctx* ctx, double* direct) {
+    EDMP_REQUIRE(ctx && ctx->unet && direct, "no model loaded");
+    *direct = ctx->unet->flops_direct;
+    return EDMP_OK;
 }
 
 extern "C" int edmp_unet_flops(edmp_ctx* ctx, double* nominal, double* executed) {

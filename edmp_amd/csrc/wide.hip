@@ -55,19 +55,48 @@ __device__ __forceinline__ void static_for(F&& f) {
 // R = (w1 - w2) x0, y0 = P + Q, y1 = P + R: the weight differences are formed once at load, x0 + x1 when the chunk is
 // staged into LDS, P / Q / R accumulate in three tiles and are combined when the epilogue reads them back - 25 % fewer
 // MFMAs on the twelve L = 2 convolutions of every forward, exact in exact arithmetic (fp32 rounding of the sums aside).
-enum WideKind { WK_K5 = 0, WK_DOWN = 1, WK_UP = 2, WK_K5K2 = 3 };
+// WK_K5K4: the Conv1dBlock at L = 4 with the same idea applied twice.  y = T x with the banded 4x4 Toeplitz matrix T of
+// the five taps; in 2x2 blocks T = [[A, B], [C, A]], so y_top = A (x_top + x_bot) + (B - A) x_bot, y_bot = A (x_top + x_bot)
+// + (C - A) x_top: three 2x2 Toeplitz products, each done in the three-product form above: 9 matrix products instead of
+// the 14 valid (tap, position) pairs of the direct form.  Nine staged positions (sums of input positions), nine weight
+// slots (signed sums of taps, formed once at load), nine accumulator tiles, each output = the sum of four of them.
+enum WideKind { WK_K5 = 0, WK_DOWN = 1, WK_UP = 2, WK_K5K2 = 3, WK_K5K4 = 4 };
 
 // MS: samples per workgroup = MFMA tile height (32 or 16); CG: output channels per workgroup; GS: channels per GroupNorm
 // group (WK_K5; CG % GS == 0); LIN: input positions; RES: fold the block's residual 1x1 conv (WK_K5)
 template <int KIND, int MS, int CG, int GS, int LIN, bool RES>
 struct WideCfg {
     static constexpr int NW = 4;                     // waves per workgroup
-    static constexpr bool K2 = (KIND == WK_K5K2);
+    static constexpr bool K2 = (KIND == WK_K5K2), K4 = (KIND == WK_K5K4);
+    static constexpr bool BIL = K2 || K4;            // bilinear (Karatsuba) form: staged positions / accumulators are sums
     static constexpr int LLOAD = LIN;                // input positions fetched from HBM per chunk
-    static constexpr int L = K2 ? 3 : LIN;           // positions staged in LDS (K2: x0, x1, x0 + x1)
-    static constexpr int LOUT = (KIND == WK_K5 || K2) ? LIN : (KIND == WK_DOWN) ? (LIN - 1) / 2 + 1 : ((2 * LIN == 8 || 2 * LIN == 14 || 2 * LIN == 26) ? 2 * LIN - 1 : 2 * LIN);
-    static constexpr int LACC = K2 ? 3 : LOUT;       // accumulator tiles per slab (K2: P, Q, R)
-    static constexpr bool GN = (KIND == WK_K5 || K2);  // GroupNorm + Mish + add epilogue (else: + bias)
+    static constexpr int L = K2 ? 3 : K4 ? 9 : LIN;  // positions staged in LDS
+    static constexpr int LOUT = (KIND == WK_K5 || BIL) ? LIN : (KIND == WK_DOWN) ? (LIN - 1) / 2 + 1 : ((2 * LIN == 8 || 2 * LIN == 14 || 2 * LIN == 26) ? 2 * LIN - 1 : 2 * LIN);
+    static constexpr int LACC = K2 ? 3 : K4 ? 9 : LOUT;  // accumulator tiles per slab
+    static constexpr bool GN = (KIND == WK_K5 || BIL);   // GroupNorm + Mish + add epilogue (else: + bias)
+    // bilinear tables.  Staged position v = sum of the input positions lp with vcoef(v, lp); accumulator a collects staged
+    // position a x weight slot a; output l = sum of the accumulators a with ocoef(l, a); rawpos(v) = lp if v IS x_lp.
+    static constexpr bool vcoef(int v, int lp) {
+        if (K2) return v == 2 || v == lp;
+        if (K4) {
+            constexpr int m[9] = {0xF, 0xA, 0x5, 0xC, 0x8, 0x4, 0x3, 0x2, 0x1};  // bit lp set: x_lp is part of the sum
+            return (m[v] >> lp) & 1;
+        }
+        return v == lp;
+    }
+    static constexpr bool ocoef(int l, int a) {
+        if (K2) return a == 0 || a == 1 + l;
+        if (K4) {
+            constexpr int m[4] = {0x01B, 0x02D, 0x0C3, 0x145};  // y0 = a0+a1+a3+a4, y1 = a0+a2+a3+a5, y2 = a0+a1+a6+a7, y3 = a0+a2+a6+a8
+            return (m[l] >> a) & 1;
+        }
+        return l == a;
+    }
+    static constexpr int rawpos(int v) {
+        if (K2) return v < 2 ? v : -1;
+        if (K4) return v == 8 ? 0 : v == 7 ? 1 : v == 5 ? 2 : v == 4 ? 3 : -1;
+        return v;
+    }
     static constexpr int SW = MS;                    // output channels per slab (MFMA tile width = height)
     static constexpr int KG = (MS == 32) ? 8 : 16;   // channels per K group = four MFMAs (K = 2 resp. 4 each)
     static constexpr int AR = (MS == 32) ? 16 : 4;   // accumulator registers per tile
@@ -78,11 +107,12 @@ struct WideCfg {
     static constexpr int QW = KC / KG / KSPLIT;      // K groups per wave per chunk
     static constexpr int LDK = KC + 4;
     static constexpr int KT0 = (KIND == WK_K5 && LIN == 2) ? 1 : 0;  // first tap that can be valid
-    static constexpr int NTAP = K2 ? 3 : (KIND == WK_K5) ? ((LIN == 2) ? 3 : 5) : (KIND == WK_DOWN) ? 3 : 4;  // weight slots per K group
+    static constexpr int NTAP = K2 ? 3 : K4 ? 9 : (KIND == WK_K5) ? ((LIN == 2) ? 3 : 5) : (KIND == WK_DOWN) ? 3 : 4;  // weight slots per K group
     static constexpr int NSLAB = NTAP + (RES ? 1 : 0);
     // weight slot of the pair (output tile l, input position lp), -1 if the tap does not exist
     static constexpr int slot(int l, int lp) {
         if (K2) return (l == 0 && lp == 2) ? 0 : (l == 1 && lp == 1) ? 1 : (l == 2 && lp == 0) ? 2 : -1;  // P, Q, R
+        if (K4) return l == lp ? l : -1;
         const int t = (KIND == WK_K5) ? lp - l + 2 - KT0 : (KIND == WK_DOWN) ? lp - 2 * l + 1 : l + 1 - 2 * lp;
         return (t >= 0 && t < NTAP) ? t : -1;
     }
@@ -90,8 +120,7 @@ struct WideCfg {
     static constexpr int NTH = NW * 64;
     static constexpr int A_F4 = LLOAD * MS * (KC / 4);  // float4 items fetched per chunk
     static constexpr int NA = (A_F4 + NTH - 1) / NTH;
-    static constexpr int NPER = MS * (KC / 4) / NTH;    // staging items of a thread per position (K2)
-    static constexpr int NCOMMIT = NA + (K2 ? NPER : 0);  // ds_writes per thread per chunk (K2: + the sum position)
+    static constexpr int NCOMMIT = BIL ? L : NA;        // ds_writes per thread per chunk (bilinear: one per STAGED position)
     static constexpr int NBL = QW * NSLAB;           // weight-fragment loads per wave per chunk
     static constexpr int YS = LACC * CG + 4;
     static constexpr int NP = KSPLIT;                // partial tiles per output element
@@ -100,6 +129,7 @@ struct WideCfg {
     static constexpr int NF4 = (ROW_F4 + PPR - 1) / PPR;
     // MFMA blocks: one per (K group q, input position lp) = all tiles fed by that A fragment (+ the residual tile)
     static constexpr int NBLK = QW * L;
+    static constexpr int NQSLOT = 4 * L * QW - L;    // bilinear K step: memory-work slots (one per (round, position), none in the last round)
     static constexpr int NSIDE = NA + NBL + NCOMMIT;  // side work items of a step: activation loads, weight loads, commits
     static constexpr int pairs() {
         int n = 0;
@@ -117,8 +147,8 @@ struct WideCfg {
     static_assert(MS == 32 || MS == 16, "tile height 32 (32x32x2 MFMA) or 16 (16x16x4 MFMA)");
     static_assert(NBLK >= 3 && 4 * (NBLK - 1) >= 1, "the memory work of a step is spread over the blocks before the last");
     static_assert(CG % SW == 0 && NW % S == 0 && S <= NW, "slabs per workgroup must divide the wave count");
-    static_assert(!RES || KIND == WK_K5 || K2, "the folded residual 1x1 conv belongs to a Conv1dBlock");
-    static_assert(!K2 || (LIN == 2 && (MS * (KC / 4)) % NTH == 0), "Karatsuba form: two positions; a thread's staging items k and k + NPER are the two positions of one (row, channel quad)");
+    static_assert(!RES || KIND == WK_K5 || BIL, "the folded residual 1x1 conv belongs to a Conv1dBlock");
+    static_assert(!BIL || (MS * (KC / 4) == NTH && (K2 ? LIN == 2 : LIN == 4)), "bilinear forms: staging item k of a thread = input position k of one (row, channel quad)");
     static_assert((LOUT * CG) % 4 == 0, "whole float4 columns");
     static_assert(!GN || CG % GS == 0, "whole GroupNorm groups per workgroup");
     static_assert(!GN || GS == CG || (4 * PPR) % CG == 0, "a thread's columns of the final pass lie in one GroupNorm group");
@@ -139,7 +169,7 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
     using Cf = WideCfg<KIND, MS, CG, GS, LIN, RES>;
     using acc_t = typename WideAcc<MS>::type;
     constexpr int L = Cf::L, LLOAD = Cf::LLOAD, LOUT = Cf::LOUT, LACC = Cf::LACC, SW = Cf::SW, KG = Cf::KG, AR = Cf::AR;
-    constexpr bool K2 = Cf::K2;
+    constexpr bool BIL = Cf::BIL;
     constexpr int NCOMMIT = Cf::NCOMMIT;
     constexpr int S = Cf::S, KC = Cf::KC, QW = Cf::QW, LDK = Cf::LDK, NTAP = Cf::NTAP, NSLAB = Cf::NSLAB;
     constexpr int A_FL = Cf::A_FL, NTH = Cf::NTH, A_F4 = Cf::A_F4, NA = Cf::NA, YS = Cf::YS, NP = Cf::NP;
@@ -200,12 +230,26 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
         for (int k = 0; k < NA; ++k) r[k] = *reinterpret_cast<const f32x4*>(src + (first ? a_g1[k] : a_g2[k]) + ci0);
     };
     auto commit_a = [&](float* st, const f32x4(&r)[NA]) __attribute__((always_inline)) {
+        if constexpr (BIL) {
+            // staged position v = sum of the fetched positions in vcoef(v, .): this thread holds all of them for its
+            // (sample row, channel quad)
+            static_for<0, L>([&](auto vc) __attribute__((always_inline)) {
+                constexpr int v = decltype(vc)::value;
+                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                bool have = false;
+                static_for<0, LLOAD>([&](auto lc) __attribute__((always_inline)) {
+                    constexpr int lp = decltype(lc)::value;
+                    if constexpr (Cf::vcoef(v, lp)) {
+                        sum = have ? sum + r[lp] : r[lp];
+                        have = true;
+                    }
+                });
+                *reinterpret_cast<f32x4*>(st + a_l[0] + v * (MS * LDK)) = sum;
+            });
+        } else {
 #pragma unroll
-        for (int k = 0; k < NA; ++k)
-            if ((A_F4 % NTH == 0) || tid + k * NTH < A_F4) *reinterpret_cast<f32x4*>(st + a_l[k]) = r[k];
-        if constexpr (K2) {  // position 2 = x0 + x1
-#pragma unroll
-            for (int j = 0; j < Cf::NPER; ++j) *reinterpret_cast<f32x4*>(st + a_l[j] + 2 * (MS * LDK)) = r[j] + r[j + Cf::NPER];
+            for (int k = 0; k < NA; ++k)
+                if ((A_F4 % NTH == 0) || tid + k * NTH < A_F4) *reinterpret_cast<f32x4*>(st + a_l[k]) = r[k];
         }
     };
     auto load_b = [&](int nc, float4(&b)[QW][NSLAB]) __attribute__((always_inline)) {
@@ -227,6 +271,11 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
     // A fragment of this lane: sample row lane % MS, channel quad lane / MS of the wave's K groups
     const int frag = (lane & (MS - 1)) * LDK + 4 * (lane / MS) + KG * QW * ks;
     float4 a4 = *reinterpret_cast<const float4*>(lds + frag);
+    float4 av[BIL ? L : 1];  // bilinear forms: the fragments of every staged position of the current K group
+    if constexpr (BIL) {
+#pragma unroll
+        for (int v = 0; v < L; ++v) av[v] = *reinterpret_cast<const float4*>(lds + frag + v * (MS * LDK));
+    }
 
     // one MFMA on component J of the current A fragment and of a weight fragment
 #define EDMP_W_MFMA(ACC, B4, J)                                                                                   \
@@ -253,17 +302,26 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
         const int ci1 = (nK == 1) ? 0 : (first1 ? KC : (1 - ch1) * KC);
         auto side = [&](auto xc) __attribute__((always_inline)) {
             constexpr int X = decltype(xc)::value;  // slot index
-            constexpr int NSLOT = 4 * (NBLK - 1);
+            constexpr int NSLOT = BIL ? Cf::NQSLOT : 4 * (NBLK - 1);
             constexpr int NX = FIRST ? NA : 0;       // extra loads of the first step
             constexpr int NXC = FIRST ? NCOMMIT : 0;  // ... and its extra commits
             constexpr int NITEM = NA + NBL + NCOMMIT + NX + NXC;
             // commit item k of a staged chunk: k < NA the fetched positions, k == NA (Karatsuba form) position 2 = x0 + x1
             auto commit_item = [&](auto kc, float* stp, const f32x4(&r)[NA]) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
-                if constexpr (k < NA) {
-                    if ((A_F4 % NTH == 0) || tid + k * NTH < A_F4) *reinterpret_cast<f32x4*>(stp + a_l[k]) = r[k];
+                if constexpr (BIL) {  // staged position k = sum of the fetched positions in vcoef(k, .)
+                    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                    bool have = false;
+                    static_for<0, LLOAD>([&](auto lc) __attribute__((always_inline)) {
+                        constexpr int lp = decltype(lc)::value;
+                        if constexpr (Cf::vcoef(k, lp)) {
+                            sum = have ? sum + r[lp] : r[lp];
+                            have = true;
+                        }
+                    });
+                    *reinterpret_cast<f32x4*>(stp + a_l[0] + k * (MS * LDK)) = sum;
                 } else {
-                    *reinterpret_cast<f32x4*>(stp + a_l[k - NA] + 2 * (MS * LDK)) = r[k - NA] + r[k - NA + Cf::NPER];
+                    if ((A_F4 % NTH == 0) || tid + k * NTH < A_F4) *reinterpret_cast<f32x4*>(stp + a_l[k]) = r[k];
                 }
             };
             static_for<0, NITEM>([&](auto jc) __attribute__((always_inline)) {
@@ -277,41 +335,89 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
                 }
             });
         };
-        static_for<0, QW>([&](auto qc) __attribute__((always_inline)) {
-            constexpr int q = decltype(qc)::value;
-            static_for<0, L>([&](auto lpc) __attribute__((always_inline)) {
-                constexpr int lp = decltype(lpc)::value;
-                constexpr int X = q * L + lp;  // block index
-                // next A fragment: (lp+1, q) | (0, q+1) | first fragment of the next chunk
-                // (the first step reads the latter after its barrier: chunk 1 is committed during that step)
-                const float* an_p = (lp + 1 < L) ? st + frag + (lp + 1) * (MS * LDK) + KG * q
-                                    : (q + 1 < QW) ? st + frag + KG * (q + 1)
-                                                   : (FIRST ? st : stn) + frag;
-                const float4 an = *reinterpret_cast<const float4*>(an_p);
-                // the block: component-major over the tiles this A fragment feeds, so that consecutive MFMAs go to
-                // different accumulators (the 16x16x4 MFMA has 40 cycles of dependent latency for 32 of issue); after
-                // each round one slot of memory work rides in the shadow of the round's last MFMA
-#define EDMP_W_COMP(J, R)                                                                                                   \
-    static_for<0, LACC>([&](auto lc) __attribute__((always_inline)) {                                                     \
-        constexpr int l = decltype(lc)::value;                                                                              \
-        if constexpr (Cf::slot(l, lp) >= 0) { EDMP_W_MFMA(acc[l], bc[q][Cf::slot(l, lp) >= 0 ? Cf::slot(l, lp) : 0], J) }   \
-    });                                                                                                                     \
-    if constexpr (RES && lp < LLOAD) { EDMP_W_MFMA(racc[lp < LLOAD ? lp : 0], bc[q][NTAP], J) }                             \
-    __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    if constexpr (X < NBLK - 1) {                                                                                           \
-        side(std::integral_constant<int, 4 * X + R>{});                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                                                  \
-    }
-                EDMP_W_COMP(x, 0)
-                EDMP_W_COMP(y, 1)
-                EDMP_W_COMP(z, 2)
-                EDMP_W_COMP(w, 3)
-#undef EDMP_W_COMP
-                a4 = an;
+        if constexpr (BIL) {
+            // Bilinear forms have ONE accumulator per staged position, so a block per position would be a chain of four
+            // dependent MFMAs with memory work after every one of them.  Instead one block per K group: all staged
+            // positions' fragments live in av[], rounds over the four fragment components, positions inside a round (=
+            // consecutive MFMAs on different accumulators), one memory-work slot after every (round, position); a
+            // position's fragment of the NEXT K group is read into place right after its last use (round w).
+            static_for<0, QW>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int q = decltype(qc)::value;
+                static_for<0, 4>([&](auto jc) __attribute__((always_inline)) {
+                    constexpr int J = decltype(jc)::value;
+                    static_for<0, L>([&](auto vc) __attribute__((always_inline)) {
+                        constexpr int v = decltype(vc)::value;
+                        const float ax = (J == 0) ? av[v].x : (J == 1) ? av[v].y : (J == 2) ? av[v].z : av[v].w;
+                        static_for<0, LACC>([&](auto ac) __attribute__((always_inline)) {
+                            constexpr int a = decltype(ac)::value;
+                            if constexpr (Cf::slot(a, v) >= 0) {
+                                const float4& bq = bc[q][Cf::slot(a, v) >= 0 ? Cf::slot(a, v) : 0];
+                                const float bx = (J == 0) ? bq.x : (J == 1) ? bq.y : (J == 2) ? bq.z : bq.w;
+                                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bx, acc[a], 0, 0, 0);
+                            }
+                        });
+                        if constexpr (RES && Cf::rawpos(v) >= 0) {
+                            const float4& bq = bc[q][NTAP];
+                            const float bx = (J == 0) ? bq.x : (J == 1) ? bq.y : (J == 2) ? bq.z : bq.w;
+                            racc[Cf::rawpos(v) >= 0 ? Cf::rawpos(v) : 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bx, racc[Cf::rawpos(v) >= 0 ? Cf::rawpos(v) : 0], 0, 0, 0);
+                        }
+                        if constexpr (J == 3 && !(FIRST && q + 1 == QW)) {
+                            const float* nx = (q + 1 < QW) ? st + frag + KG * (q + 1) : stn + frag;
+                            av[v] = *reinterpret_cast<const float4*>(nx + v * (MS * LDK));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        constexpr int X = (q * 4 + J) * L + v;
+                        if constexpr (X < Cf::NQSLOT) {
+                            side(std::integral_constant<int, X>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    });
+                });
             });
-        });
+        } else {
+        static_for<0, QW>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int q = decltype(qc)::value;
+                static_for<0, L>([&](auto lpc) __attribute__((always_inline)) {
+                    constexpr int lp = decltype(lpc)::value;
+                    constexpr int X = q * L + lp;  // block index
+                    // next A fragment: (lp+1, q) | (0, q+1) | first fragment of the next chunk
+                    // (the first step reads the latter after its barrier: chunk 1 is committed during that step)
+                    const float* an_p = (lp + 1 < L) ? st + frag + (lp + 1) * (MS * LDK) + KG * q
+                                        : (q + 1 < QW) ? st + frag + KG * (q + 1)
+                                                       : (FIRST ? st : stn) + frag;
+                    const float4 an = *reinterpret_cast<const float4*>(an_p);
+                    // the block: component-major over the tiles this A fragment feeds, so that consecutive MFMAs go to
+                    // different accumulators (the 16x16x4 MFMA has 40 cycles of dependent latency for 32 of issue); after
+                    // each round one slot of memory work rides in the shadow of the round's last MFMA
+    #define EDMP_W_COMP(J, R)                                                                                                   \
+        static_for<0, LACC>([&](auto lc) __attribute__((always_inline)) {                                                     \
+            constexpr int l = decltype(lc)::value;                                                                              \
+            if constexpr (Cf::slot(l, lp) >= 0) { EDMP_W_MFMA(acc[l], bc[q][Cf::slot(l, lp) >= 0 ? Cf::slot(l, lp) : 0], J) }   \
+        });                                                                                                                     \
+        if constexpr (RES && lp < LLOAD) { EDMP_W_MFMA(racc[lp < LLOAD ? lp : 0], bc[q][NTAP], J) }                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        if constexpr (X < NBLK - 1) {                                                                                           \
+            side(std::integral_constant<int, 4 * X + R>{});                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                                  \
+        }
+                    EDMP_W_COMP(x, 0)
+                    EDMP_W_COMP(y, 1)
+                    EDMP_W_COMP(z, 2)
+                    EDMP_W_COMP(w, 3)
+    #undef EDMP_W_COMP
+                    a4 = an;
+                });
+            });
+        }
         __syncthreads();
-        if constexpr (FIRST) a4 = *reinterpret_cast<const float4*>(stn + frag);
+        if constexpr (FIRST) {
+            if constexpr (BIL) {
+#pragma unroll
+                for (int v = 0; v < L; ++v) av[v] = *reinterpret_cast<const float4*>(stn + frag + v * (MS * LDK));
+            } else {
+                a4 = *reinterpret_cast<const float4*>(stn + frag);
+            }
+        }
     };
 
     {
@@ -386,7 +492,7 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
 #pragma unroll
     for (int l = 0; l < LACC; ++l)
 #pragma unroll
-        for (int r = 0; r < AR; ++r) Yw[acc_row(r) * YS + l * CG] = acc[l][r] + ((K2 && l > 0) ? 0.0f : bias_v);  // K2: the bias rides in P
+        for (int r = 0; r < AR; ++r) Yw[acc_row(r) * YS + l * CG] = acc[l][r] + ((BIL && l > 0) ? 0.0f : bias_v);  // bilinear: the bias rides in accumulator 0, part of every output exactly once
     __syncthreads();
     EDMP_STAMP(0, 3)
     {
@@ -398,15 +504,27 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
             const int f = epart + PPR * i;
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((ROW_F4 % PPR == 0) || f < ROW_F4) {
-                if constexpr (K2) {
-                    // output position l of channel quad c: y0 = P + Q, y1 = P + R (tiles 0 | 1 | 2 of the partial buffers)
-                    const int col = 4 * f, l = col / CG, c = col % CG;
+                if constexpr (BIL) {
+                    // output position l of channel quad c = sum of the accumulator tiles in ocoef(l, .); l is static per i
+                    // (a thread's i-th float4 lies 4 * PPR * i columns further)
+                    static_assert(4 * PPR <= CG && CG % (4 * PPR) == 0, "bilinear combine: output position static per item");
+                    const int c = (4 * f) % CG;
+                    static_for<0, LACC>([&](auto ac) __attribute__((always_inline)) {
+                        constexpr int a = decltype(ac)::value;
+                        static_for<0, NF4>([&](auto ic) __attribute__((always_inline)) {
+                            constexpr int ii = decltype(ic)::value;
+                            if (ii == i) {
+                                constexpr int lout = (4 * PPR * ii) / CG;
+                                if constexpr (lout < LOUT && Cf::ocoef(lout < LOUT ? lout : 0, a)) {
 #pragma unroll
-                    for (int q = 0; q < NP; ++q) {
-                        const float4 pp = *reinterpret_cast<const float4*>(Y + q * (MS * YS) + erow * YS + c);
-                        const float4 pq = *reinterpret_cast<const float4*>(Y + q * (MS * YS) + erow * YS + (1 + l) * CG + c);
-                        v[i].x += pp.x + pq.x, v[i].y += pp.y + pq.y, v[i].z += pp.z + pq.z, v[i].w += pp.w + pq.w;
-                    }
+                                    for (int q = 0; q < NP; ++q) {
+                                        const float4 pv = *reinterpret_cast<const float4*>(Y + q * (MS * YS) + erow * YS + a * CG + c);
+                                        v[i].x += pv.x, v[i].y += pv.y, v[i].z += pv.z, v[i].w += pv.w;
+                                    }
+                                }
+                            }
+                        });
+                    });
                 } else {
                     v[i] = *reinterpret_cast<const float4*>(Y + erow * YS + 4 * f);
 #pragma unroll
@@ -506,6 +624,36 @@ inline void pack_fragments_k2(const float* w_tco_ci, int cout, int cin, bool res
         if (res) t[5 * n + i] = w_tco_ci[5 * n + i];
     }
     pack_fragments(t.data(), cout, cin, 0, 3, res, out, 32);
+}
+
+// nested Karatsuba form of the L = 4 Conv1dBlock (WK_K5K4): nine weight slots = signed sums of the five taps
+// (rows: slot, columns: tap 0..4), formed in double and rounded once; then the fragment stream of pack_fragments
+inline void pack_fragments_k4(const float* w_tco_ci, int cout, int cin, bool res, float* out) {
+    static const int wc[9][5] = {{0, 0, 1, 0, 0},   {0, 0, -1, 1, 0},  {0, 1, -1, 0, 0},  {0, 0, -1, 0, 1}, {0, 0, 1, -1, -1},
+                                 {0, -1, 1, 1, -1}, {1, 0, -1, 0, 0},  {-1, 1, 1, -1, 0}, {-1, -1, 1, 0, 0}};
+    const int nslot = 9 + (res ? 1 : 0);
+    const size_t n = (size_t)cout * cin;
+    std::vector<float> t((size_t)nslot * n, 0.0f);
+    for (size_t i = 0; i < n; ++i) {
+        for (int sl = 0; sl < 9; ++sl) {
+            double a = 0.0;
+            for (int k = 0; k < 5; ++k) a += wc[sl][k] * (double)w_tco_ci[(size_t)k * n + i];
+            t[(size_t)sl * n + i] = (float)a;
+        }
+        if (res) t[(size_t)9 * n + i] = w_tco_ci[(size_t)5 * n + i];
+    }
+    // pack_fragments reads slot t < ntap from tap index kt0 + t and the residual from tap index 5: lay the ten slabs out so
+    const int nkg = cin / 8;
+    for (int sl = 0; sl < cout / 32; ++sl)
+        for (int kg = 0; kg < nkg; ++kg)
+            for (int ts = 0; ts < nslot; ++ts) {
+                float* o = out + (((size_t)sl * nkg + kg) * nslot + ts) * 256;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int nn = lane % 32, kh = lane / 32;
+                    const float* src = t.data() + ((size_t)ts * cout + sl * 32 + nn) * cin + 8 * kg + 4 * kh;
+                    for (int j = 0; j < 4; ++j) o[lane * 4 + j] = src[j];
+                }
+            }
 }
 
 template <int KIND, int MS, int CG, int GS, int LIN, bool RES>

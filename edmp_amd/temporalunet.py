@@ -164,6 +164,13 @@ class TemporalUNet:
         weights.write_packed(path, layout.value, self.input_dim, self.time_dim, self.dims, self.horizon, self.T, blob)
         return path
 
+    def flops_direct_form(self):
+        """FLOPs per trajectory of the direct convolution without padding taps (see edmp_unet_flops_direct)."""
+        self._bind()
+        d = C.c_double()
+        _capi.check(self.ctx.lib.edmp_unet_flops_direct(self.ctx.h, C.byref(d)))
+        return d.value
+
     def save(self):
         if self._flat is None:  # constructed from a packed image: the state dict lives in the checkpoint next to it
             self._flat = self._flatten(weights.load_checkpoint_dir(self.model_name))

@@ -79,6 +79,10 @@ int edmp_unet_read_activation_dev(edmp_ctx* ctx, int which, int B, float* out_de
  * arithmetic (SURVEY.md §8d, 187 339 904 for the full net); (b) executed = taps that fall in the zero padding are
  * skipped by the kernels */
 int edmp_unet_flops(edmp_ctx* ctx, double* nominal, double* executed);
+/* FLOPs per trajectory of the DIRECT convolution with the taps that only ever meet zero padding removed (round 1's
+ * "executed" figure, 122.0 MFLOP for the full-size net).  edmp_unet_flops' `executed` counts the MFMA work actually
+ * issued, which is lower where the L = 2 / L = 4 convolutions run in Karatsuba form (wide.hip). */
+int edmp_unet_flops_direct(edmp_ctx* ctx, double* direct);
 
 /* ---- guide: IntersectionVolumeGuide -------------------------------------------------------------------- */
 /* replaces IntersectionVolumeGuide.__init__/define_link_information/define_obstacles

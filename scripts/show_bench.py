@@ -12,7 +12,7 @@ d = json.loads(lines[-1])
 print(f"value {d['value']:.0f} {d['unit']}  ms_per_step {d['ms_per_step']:.2f}  n_gpus {d['n_gpus']}  | {d['config']['parallelism'][:100]}")
 r = d.get("roofline")
 if r:
-    print(f"roofline: executed {r['achieved']:.1f} TF/s = {r['frac']:.3f} of {r['peak']}; nominal {r['achieved_nominal']:.1f}; conv {r['conv_ms_per_call']:.1f} ms "
+    print(f"roofline: issued {r['achieved']:.1f} TF/s = {r['frac']:.3f} of {r['peak']}; direct-form {r.get('achieved_direct_form', 0):.1f} = {r.get('frac_direct_form', 0):.3f}; nominal {r['achieved_nominal']:.1f}; conv {r['conv_ms_per_call']:.1f} ms "
           f"({r['conv_share_of_step']:.3f} of the step) over {r['launches']} launches, avg {r['avg_launch_us']:.2f} us; timing {r['timing']}")
     for row in r["per_kernel"]:
         print(f"  {row['kernel']:46s} n={row['launches']:5d} avg {row['avg_us']:7.2f} us share {row['share']:.3f} {row['executed_tflops']:6.1f} TF frac {row['frac']:.3f}")

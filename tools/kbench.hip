@@ -70,6 +70,7 @@ static void run_wide(int B, int C1, int C2, bool with_res_add) {
     using Cf = WideCfg<KIND, MS, CG, GS, L, RES>;
     std::vector<float> hWf((size_t)(Cout / Cf::SW) * (Cin / Cf::KG) * Cf::NSLAB * 256);
     if constexpr (KIND == WK_K5K2) pack_fragments_k2(hW.data(), Cout, Cin, RES, hWf.data());
+    else if constexpr (KIND == WK_K5K4) pack_fragments_k4(hW.data(), Cout, Cin, RES, hWf.data());
     else pack_fragments(hW.data(), Cout, Cin, Cf::KT0, Cf::NTAP, RES, hWf.data(), Cf::SW);
     float *W = up(hW), *Wf = up(hWf), *x1 = up(hx1), *x2 = up(hx2), *bias = up(hb), *gam = up(hg), *bet = up(hbe), *tb = up(htb), *rb = up(hrb), *res = up(hres);
     float *d_old, *d_new, *r_old, *r_new;
@@ -140,7 +141,7 @@ static void run_wide(int B, int C1, int C2, bool with_res_add) {
         t_new = std::min(t_new, time_us(f_new, 50));
     }
     const double fl = 2.0 * B * (double)Cout * Cin * (Cf::valid_pairs() + (RES ? L : 0));
-    printf("k5%s<MS%d,cg%2d,L%2d,res%d> Cin=%4d+%4d  max|d| %.2e (ref %.1f) res %.2e | old %7.2f us %6.1f TF | new %7.2f us %6.1f TF (%.3f of 157.3) | x%.3f\n", KIND == WK_K5K2 ? "-karatsuba" : "", MS, GS, L,
+    printf("k5%s<MS%d,cg%2d,L%2d,res%d> Cin=%4d+%4d  max|d| %.2e (ref %.1f) res %.2e | old %7.2f us %6.1f TF | new %7.2f us %6.1f TF (%.3f of 157.3) | x%.3f\n", KIND == WK_K5K2 ? "-karatsuba" : KIND == WK_K5K4 ? "-karatsuba4" : "", MS, GS, L,
            (int)RES, C1, C2, d1, rm, d2, t_old, fl / t_old / 1e6, t_new, fl / t_new / 1e6, fl / t_new / 1e6 / 157.3, t_old / t_new);
 #ifdef EDMP_STAMPS
     {
@@ -334,6 +335,10 @@ int main(int argc, char** argv) {
     run_wide<32, 64, 64, 2, true>(B, 512, 512, false);
     run_wide<32, 64, 64, 2, false, WK_K5K2>(B, 512, 0, true);
     run_wide<32, 64, 64, 2, true, WK_K5K2>(B, 512, 512, false);
+    run_wide<32, 64, 64, 4, false, WK_K5K4>(B, 512, 0, false);
+    run_wide<32, 64, 64, 4, true, WK_K5K4>(B, 256, 0, false);
+    run_wide<32, 32, 32, 4, false, WK_K5K4>(B, 256, 0, true);
+    run_wide<32, 32, 32, 4, true, WK_K5K4>(B, 512, 512, false);
     run_wide<32, 64, 64, 4, false>(B, 512, 0, false);
     run_wide<32, 64, 64, 4, true>(B, 256, 0, false);
     run_wide<32, 32, 32, 4, false>(B, 256, 0, true);
