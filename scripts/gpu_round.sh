@@ -1,19 +1,23 @@
 #!/bin/bash
-# run on the GPU box by gpurun: bench, rocprofv3 kernel trace of the same command, PMC passes (outputs -> gpurun_out/)
-mkdir -p gpurun_out
-python bench.py --steps 3 --warmup 1 > gpurun_out/bench.json 2> gpurun_out/bench.err
-tail -2 gpurun_out/bench.err | grep -v amdgpu.ids
-cat gpurun_out/bench.json
+# Run on the GPU box by gpurun: bench.py, the rocprofv3 kernel trace of the same command, and the PMC passes
+# (FETCH_SIZE / WRITE_SIZE / MFMA busy, each its own run, --kernel-trace only).  Outputs -> gpurun_out/r02/.
+O=gpurun_out/r02
+mkdir -p $O
+python bench.py --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err
+python scripts/show_bench.py $O/bench.json | cut -c1-220 | head -4
 export TMPDIR=/tmp
 REPO=$PWD
 CMD="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline"
 cd /tmp
-rm -rf $REPO/gpurun_out/prof $REPO/gpurun_out/pmc_FETCH_SIZE $REPO/gpurun_out/pmc_WRITE_SIZE
-rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof -o trace -- $CMD > $REPO/gpurun_out/prof_bench.json 2> $REPO/gpurun_out/prof.err
+rm -rf $REPO/$O/prof $REPO/$O/pmc_*
+rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$O/prof -o trace -- $CMD > $REPO/$O/prof_bench.json 2> $REPO/$O/prof.err
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $REPO/gpurun_out/pmc_$c -o p -- python $REPO/scripts/pmc_unet_forward.py > /dev/null 2> $REPO/gpurun_out/pmc_$c.err
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $REPO/$O/pmc_$c -o p -- python $REPO/scripts/pmc_unet_forward.py > /dev/null 2> $REPO/$O/pmc_$c.err
 done
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $REPO/$O/pmc_mfma -o p -- python $REPO/scripts/pmc_unet_forward.py > /dev/null 2> $REPO/$O/pmc_mfma.err
 cd $REPO
-rm -f gpurun_out/prof/trace_kernel_trace.csv gpurun_out/pmc_*/p_kernel_trace.csv
-python scripts/summarize_profiles.py gpurun_out | head -12
-python scripts/summarize_pmc.py gpurun_out gpurun_out/pmc_hbm_traffic.json 3
+cp $(find $O/prof -name "trace_kernel_stats.csv" | head -1) $O/kernel_stats.csv 2>/dev/null
+python scripts/summarize_profiles.py $O | head -8
+python scripts/summarize_pmc.py $O $O/pmc_hbm_traffic.json 3
+python scripts/summarize_mfma_pmc.py $(find $O/pmc_mfma -name "*counter_collection.csv" | head -1) $O/pmc_mfma_util.md | tail -12
+rm -f $(find $O -name "*kernel_trace.csv") $(find $O -name "*counter_collection.csv")

@@ -37,7 +37,7 @@ for k, v in sorted(res.items(), key=lambda kv: -kv[1]["fetch_kib"]):
     write = v["write_kib"] * 1024
     rows.append(dict(kernel=k, launches=v["launches"], fetch_MB_per_launch_corrected=fetch / 1e6 / max(v["launches"], 1),
                      write_MB_per_launch=write / 1e6 / max(v["wl"], 1)))
-    if "conv" in k or "rcb" in k:
+    if "conv" in k or "rcb" in k or "level" in k:
         conv_bytes += fetch + write
         conv_launches += v["launches"]
 summary = dict(
