@@ -3,21 +3,18 @@
 // Replaces TemporalUNet.forward and the blocks it is built from (reference: diffusion/models/temporalunet.py:47-76,
 // diffusion/models/blocks.py:13-34 Conv1dBlock, :38-92 time embedding, :137-166 ResidualConvolutionBlock,
 // :202-260 Down/Middle/Up samplers).  Design:
-//   * activations live in HBM as [B][L][C] fp32 (channels innermost) so that every conv tap of one output position
-//     is a contiguous C-vector per sample; conv weights are repacked once to [tap][Cout][Cin].
-//   * all matrix work is v_mfma_f32_32x32x2_f32 (exact fp32).  Four kernel families:
-//       rcb_conv_kernel  wide levels (Cout 256/512, L 2/4/7): Conv1d k5 + bias + GroupNorm + Mish + add, one launch
-//                        (+ the block's residual 1x1 conv folded in); workgroup = 32 samples x one GroupNorm group x
-//                        all L positions; split-K wave ownership where a group is one 32-channel slab.
-//       rcb_rows_kernel  narrow levels (Cout <= 128, L 7..50): the same fusion with GEMM rows = (sample, position);
-//                        workgroup = a few whole samples x 32/64 channels, taps read from one zero-haloed LDS tile.
-//       rcb_block_kernel the 32/64-channel levels: a whole ResidualConvolutionBlock per launch (hidden activation in LDS).
-//       conv_mfma_kernel everything else (k3 s2, ConvTranspose k4 s2, the two remaining 1x1 residual convs): implicit
-//                        GEMM per output position; also the whole net with gn_mish_kernel when EDMP_NO_FUSED=1.
-//     Taps that fall into the zero padding are never issued (at L=2 only 2 of 5 taps exist): 122.0 of the 187.3
-//     nominal MFLOP per trajectory-step are executed.
+//   * activations live in HBM as [B][L][C] fp32 (channels innermost); conv weights are repacked once at load into MFMA
+//     B-fragment streams (wide.hip: pack_fragments) that the kernels read straight into registers.
+//   * all matrix work is exact-fp32 MFMA.  Round-2 kernel families of the full-size network (42 launches per forward):
+//       wide_conv_kernel (wide.hip)   every level with >= 128 channels: the position-tile kernel - Conv1d k5 + bias +
+//                                     GroupNorm + Mish + add (+ folded residual 1x1 conv), k3s2 / ConvTranspose resamplers,
+//                                     Karatsuba forms at L = 2 / L = 4
+//       level_kernel (level.hip)      the 32/64-channel levels: two residual blocks + resampling conv (+ final conv) per launch
+//     and, for architectures those have no instance for (the tiny test networks) or EDMP_NO_FUSED / EDMP_NO_LEVEL runs, the
+//     round-1 kernels of this file: conv_mfma_kernel (generic implicit GEMM), rcb_rows_kernel, rcb_block_kernel, gn_mish_kernel.
+//     Taps that fall into the zero padding are never issued.
 //   * the whole time-embedding MLP chain depends on t only and is precomputed for t = 1..T at load (time_table_kernel).
-//   * the layer program (which kernel, which buffers) is built once in edmp_unet_load; a forward is 53 conv launches (+ input pack and head).
+//   * the layer program (which kernel, which buffers) is built once in edmp_unet_load / edmp_unet_load_packed.
 #include "common.h"
 
 namespace edmp {
