@@ -151,6 +151,7 @@ struct RcbP {
     // the five conv taps in W (tap index 5); res_out [B][L][Cout] receives conv + res_bias for conv2's epilogue
     float* res_out;
     const float* res_bias;
+    int gx = 0;  // wide_conv_kernel: XCDs across the channel groups (wide.hip: xcd_split), set by the launcher
 };
 
 struct BlkP {

@@ -29,7 +29,8 @@
 //     barrier and no wave waits for LDS latency behind a barrier; one barrier per chunk.
 //   * the step's global loads (activation chunk k+2 -> staging registers, weight fragments of chunk k+1) and the
 //     ds_writes of the staged chunk are spread over the step, between the MFMA blocks of the input positions.
-// grid = (Cout / CG, ceil(B / MS)); blockIdx.x = channel group, so one XCD's L2 serves one group's weight stream.
+// grid = Cout / CG channel groups x ceil(B / MS) sample tiles, dealt to the 8 XCDs so that the sum of weight and activation
+// fetches over the 8 L2s is least (xcd_split).
 #pragma once
 #include <type_traits>
 
@@ -181,8 +182,23 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s = wave % S, ks = wave / S;
-    const int co0 = blockIdx.x * CG;
-    const int b0 = blockIdx.y * MS;
+    // workgroup -> (channel group, sample tile).  Consecutive workgroup ids go round-robin over the 8 XCDs (each with its own
+    // L2): p.gx of the XCDs split the channel groups, 8 / p.gx split the sample tiles, so a weight stream is fetched from HBM by
+    // 8 / gx L2s and an activation tile by gx of them - the host picks the split with the least traffic (unet.hip: xcd_split)
+    int grp, tile;
+    {
+        const int lin = blockIdx.x, ng = p.Cout / CG;
+        if (p.gx > 0) {
+            const int xcd = lin & 7, j = lin >> 3, tx = 8 / p.gx, ngp = ng / p.gx;
+            grp = (j % ngp) * p.gx + xcd % p.gx;
+            tile = (j / ngp) * tx + xcd / p.gx;
+        } else {
+            grp = lin % ng;
+            tile = lin / ng;
+        }
+    }
+    const int co0 = grp * CG;
+    const int b0 = tile * MS;
     const int ch1 = p.C1 / KC, ch2 = p.C2 / KC;
     const int nK = ch1 + ch2;
     const int NKG = (p.C1 + p.C2) / KG;
@@ -200,7 +216,7 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
         a_l[k] = lp * (MS * LDK) + row * LDK + c4;
     }
     // ---- weight fragment stream of this wave
-    const float* wb = p.W + ((size_t)(blockIdx.x * S + s) * NKG) * (NSLAB * 256) + lane * 4;
+    const float* wb = p.W + ((size_t)(grp * S + s) * NKG) * (NSLAB * 256) + lane * 4;
 
     acc_t acc[LACC];
     acc_t racc[RES ? LLOAD : 1];
@@ -656,6 +672,22 @@ inline void pack_fragments_k4(const float* w_tco_ci, int cout, int cin, bool res
             }
 }
 
+// How the 8 XCDs split a (channel groups x sample tiles) grid: gx of them across the groups, 8 / gx across the tiles.
+// HBM fetches = weights x (8 / gx) + activations x gx (each L2 fetches what its workgroups touch); 0 = grid does not divide.
+// EDMP_XCD_SPLIT=<gx> forces one split (ablation).
+inline int xcd_split(int ng, int nt, double w_elems, double a_elems) {
+    static const int forced = [] { const char* e = getenv("EDMP_XCD_SPLIT"); return e ? atoi(e) : -1; }();
+    int best = 0;
+    double cost = 0.0;
+    for (int gx = 1; gx <= 8; gx *= 2) {
+        if (ng % gx || nt % (8 / gx)) continue;
+        if (forced >= 0 && gx != forced) continue;
+        const double c = w_elems * (8 / gx) + a_elems * gx;
+        if (!best || c < cost) best = gx, cost = c;
+    }
+    return best;
+}
+
 template <int KIND, int MS, int CG, int GS, int LIN, bool RES>
 static int launch_wide_t(const RcbP& p, hipStream_t s) {
     static bool attr_set = false;
@@ -665,8 +697,10 @@ static int launch_wide_t(const RcbP& p, hipStream_t s) {
         EDMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_conv_kernel<KIND, MS, CG, GS, LIN, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         attr_set = true;
     }
-    dim3 grid(p.Cout / CG, (p.B + MS - 1) / MS);
-    hipLaunchKernelGGL((wide_conv_kernel<KIND, MS, CG, GS, LIN, RES>), grid, dim3(256), bytes, s, p);
+    const int ng = p.Cout / CG, nt = (p.B + MS - 1) / MS;
+    RcbP q = p;
+    q.gx = xcd_split(ng, nt, (double)p.Cout * (p.C1 + p.C2) * WideCfg<KIND, MS, CG, GS, LIN, RES>::NSLAB, (double)nt * MS * WideCfg<KIND, MS, CG, GS, LIN, RES>::LLOAD * (p.C1 + p.C2));
+    hipLaunchKernelGGL((wide_conv_kernel<KIND, MS, CG, GS, LIN, RES>), dim3(ng * nt), dim3(256), bytes, s, q);
     return EDMP_OK;
 }
 
