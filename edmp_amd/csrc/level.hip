@@ -24,6 +24,8 @@
 //     dependent latency for 32 of issue).
 // grid = ceil(B / SB) workgroups of 256 threads.
 #pragma once
+#include "params.h"
+#include "wide.hip"  // static_for, pack_fragments
 
 namespace edmp {
 
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(256) void level_kernel(LevelP p) {
 }
 
 template <int MODE, int C, int L, int SB, int CIN>
-static int launch_level_t(const LevelP& p, hipStream_t s) {
+int launch_level_t(const LevelP& p, hipStream_t s) {
     static bool attr_set = false;
     EDMP_REQUIRE(p.C1 + p.C2 == CIN && p.C1 % 4 == 0 && p.C2 % 4 == 0, "level kernel built for %d stored input channels, got %d + %d", CIN, p.C1, p.C2);
     constexpr size_t bytes = LevelCfg<MODE, C, L, SB, CIN>::lds_bytes();

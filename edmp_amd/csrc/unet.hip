@@ -16,6 +16,8 @@
 //   * the whole time-embedding MLP chain depends on t only and is precomputed for t = 1..T at load (time_table_kernel).
 //   * the layer program (which kernel, which buffers) is built once in edmp_unet_load / edmp_unet_load_packed.
 #include "common.h"
+#define EDMP_STAMPS_DEFINE 1  // unity builds with -DEDMP_STAMPS: the stamp buffer lives here
+#include "params.h"
 
 namespace edmp {
 
@@ -112,93 +114,6 @@ static RawNet inventory(const edmp_unet_desc& d) {
 // ---------------------------------------------------------------------------------------------------------------
 // device program
 // ---------------------------------------------------------------------------------------------------------------
-struct ConvP {
-    const float* src1;
-    const float* src2;  // second half of a channel concat, or nullptr
-    int C1, C2;         // channels of src1 / src2 (storage widths)
-    int Lin, Lout;
-    int ntaps, stride, pad, transposed;
-    const float* W;  // [tap][Cout][C1 + C2]
-    const float* bias;
-    float* dst;  // [B][Lout][Cout]
-    int Cout;
-    int B;
-};
-
-struct GnP {
-    float* y;  // [B][L][C], normalised in place
-    const float* gamma;
-    const float* beta;
-    const float* add_res;    // [B][L][C] or nullptr
-    const float* add_tbias;  // [C] (already offset to step t) or nullptr
-    int L, C, B;
-};
-
-struct RcbP {
-    const float* src1;
-    const float* src2;
-    int C1, C2;
-    const float* W;  // [5][Cout][C1+C2]
-    const float* bias;
-    const float* gamma;
-    const float* beta;
-    const float* add_tb;   // [Cout] time bias of step t, or nullptr
-    const float* add_res;  // [B][L][Cout] residual, or nullptr
-    float* dst;            // [B][L][Cout]
-    int Cout;
-    int B;
-    // folded residual 1x1 conv of the block input (rcb_conv_kernel<.,.,true>): its weights [Cout][Cin] sit right behind
-    // the five conv taps in W (tap index 5); res_out [B][L][Cout] receives conv + res_bias for conv2's epilogue
-    float* res_out;
-    const float* res_bias;
-    int gx = 0;  // wide_conv_kernel: XCDs across the channel groups (wide.hip: xcd_split), set by the launcher
-};
-
-struct BlkP {
-    const float* src1;
-    const float* src2;
-    int C1, C2;
-    const float* W1;  // [5][C][Cin]
-    const float* b1;
-    const float* g1;
-    const float* be1;
-    const float* tb;  // [C] time bias of step t
-    const float* W2;  // [5][C][C]
-    const float* b2;
-    const float* g2;
-    const float* be2;
-    const float* Wr;  // [C][Cin] residual 1x1 conv (RES) or nullptr (identity: src1 is the residual)
-    const float* br;
-    float* dst;  // [B][L][C]
-    int B;
-};
-
-// whole-level kernel (level.hip)
-enum LevelMode { LV_DOWN = 0, LV_UP = 1, LV_UP_FINAL = 2 };
-
-struct LevelP {
-    const float* src1;  // [B][L][C1]
-    const float* src2;  // [B][L][C2] concatenated behind src1 on the channel axis, or nullptr
-    int C1, C2;
-    // weight fragment streams (pack_fragments, sw = 16: [C/16][K/16][slots][64][4])
-    const float* w11;   // RCB1 conv1, K = KX, slots 0..4 = taps, slot 5 = the residual 1x1 conv
-    const float* w12;   // RCB1 conv2, K = C
-    const float* w21;   // RCB2 conv1
-    const float* w22;   // RCB2 conv2
-    const float* wrs;   // resampling conv: k3 s2 (3 slots) | ConvTranspose k4 s2 (4 slots)
-    const float* wfin;  // final Conv1dBlock (LV_UP_FINAL)
-    // per-channel vectors [C]: conv bias, GroupNorm gamma / beta, time bias of step t, residual-conv bias
-    const float *b11, *g11, *be11, *tb1, *rb1;
-    const float *b12, *g12, *be12;
-    const float *b21, *g21, *be21, *tb2;
-    const float *b22, *g22, *be22;
-    const float* brs;
-    const float *bfin, *gfin, *befin;
-    float* skip_out;  // [B][L][C] output of the second block (the level's skip tensor), or nullptr
-    float* out;       // [B][LOUT][C] (LV_UP_FINAL: the final Conv1dBlock's output at the up-sampled length)
-    int B;
-};
-
 enum OpKind { OP_CONV = 0, OP_GN = 1, OP_RCB = 2, OP_BLK = 3, OP_WRS = 4, OP_LVL = 5 };  // OP_LVL: a whole 32/64-channel level (level.hip)  // OP_WRS: down/up-sampling conv of a wide level on wide_conv_kernel
 struct Op {
     OpKind kind;
@@ -256,16 +171,6 @@ __global__ void pack_input_kernel(const float* __restrict__ x, float* __restrict
     out[i] = (c < C) ? x[((size_t)b * C + c) * N + l] : 0.0f;
 }
 
-#ifdef EDMP_STAMPS  // phase timing experiment (scratch builds only): one wave of one mid-grid workgroup stamps s_memtime
-__device__ unsigned long long g_stamps[8][16];
-#define EDMP_STAMP(k, i)                                                        \
-    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == gridDim.y / 2) { \
-        g_stamps[k][2 * (i)] = clock64();                                       \
-        g_stamps[k][2 * (i) + 1] = wall_clock64();                              \
-    }
-#else
-#define EDMP_STAMP(k, i)
-#endif
 
 // Implicit-GEMM Conv1d / ConvTranspose1d on the fp32 MFMA.  Block = 256 threads = 4 waves, tile BM samples x BN
 // output channels at ONE output position; K runs over (valid tap, source, channel chunk of KC).
@@ -472,6 +377,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
 }  // namespace edmp
 #include "wide.hip"
 #include "level.hip"
+#ifdef EDMP_SHARDED  // the position-tile and whole-level kernels are compiled in parallel translation units (kernel_shard.hip)
+#include "kernel_instances.h"
+namespace edmp {
+#define EDMP_X(sh, K, MS, CG, GS, L, R) extern template int launch_wide_t<K, MS, CG, GS, L, R>(const RcbP&, hipStream_t);
+EDMP_WIDE_INSTANCES(EDMP_X)
+#undef EDMP_X
+#define EDMP_X(sh, M, C, L, SB, CIN) extern template int launch_level_t<M, C, L, SB, CIN>(const LevelP&, hipStream_t);
+EDMP_LEVEL_INSTANCES(EDMP_X)
+#undef EDMP_X
+}  // namespace edmp
+#endif
 namespace edmp {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1307,7 +1223,7 @@ static bool karatsuba_l4() {
 static bool rcb_supported(int cout, int L, int c1, int c2) {
     const int cg = cout / 8;
     const bool shape = (cg == 64 && (L == 2 || L == 4)) || (cg == 32 && (L == 4 || L == 7)) || (cg == 16 && (L == 7 || L == 13));
-    return shape && cout % 8 == 0 && c1 % 32 == 0 && c2 % 32 == 0;
+    return shape && cout % 8 == 0 && c1 % 32 == 0 && c2 % 32 == 0 && (c2 == 0 || c2 == c1);  // wide.hip: equal halves of a concat
 }
 template <int CB, int L, int SB, int KC>
 static int launch_rows_t(const RcbP& p, hipStream_t s) {

@@ -34,6 +34,8 @@
 #pragma once
 #include <type_traits>
 
+#include "params.h"
+
 namespace edmp {
 
 // native 16-byte vector for register staging (a float4 STRUCT copied global -> array -> LDS stays a memcpy through
@@ -183,16 +185,18 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s = wave % S, ks = wave / S;
     // workgroup -> (channel group, sample tile).  Consecutive workgroup ids go round-robin over the 8 XCDs (each with its own
-    // L2): p.gx of the XCDs split the channel groups, 8 / p.gx split the sample tiles, so a weight stream is fetched from HBM by
+    // L2): gx = 2^gx_shift of the XCDs split the channel groups, 8 / gx split the sample tiles, so a weight stream is fetched from HBM by
     // 8 / gx L2s and an activation tile by gx of them - the host picks the split with the least traffic (unet.hip: xcd_split)
     int grp, tile;
     {
-        const int lin = blockIdx.x, ng = p.Cout / CG;
-        if (p.gx > 0) {
-            const int xcd = lin & 7, j = lin >> 3, tx = 8 / p.gx, ngp = ng / p.gx;
-            grp = (j % ngp) * p.gx + xcd % p.gx;
-            tile = (j / ngp) * tx + xcd / p.gx;
+        // (shifts, not divisions: a runtime integer division is ~40 instructions in front of the first load)
+        const int lin = blockIdx.x;
+        if (p.gx_shift >= 0) {  // ng and gx are powers of two
+            const int xcd = lin & 7, j = lin >> 3, ngp_shift = p.ng_shift - p.gx_shift;
+            grp = ((j & ((1 << ngp_shift) - 1)) << p.gx_shift) + (xcd & ((1 << p.gx_shift) - 1));
+            tile = ((j >> ngp_shift) << (3 - p.gx_shift)) + (xcd >> p.gx_shift);
         } else {
+            const int ng = p.Cout / CG;
             grp = lin % ng;
             tile = lin / ng;
         }
@@ -204,19 +208,42 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
     const int NKG = (p.C1 + p.C2) / KG;
 
     // ---- activation staging map (chunk invariant): item e = tid + k*NTH -> (position, sample row, channel quad)
-    int a_g1[NA], a_g2[NA], a_l[NA];
+    // global byte offsets of the item's float4 within chunk 0 of source 1 / source 2 (32-bit, added to a uniform base:
+    // the loads take the scalar-base + vector-offset form, no per-load address arithmetic), LDS float offset in a stage
+    unsigned a_g1[NA];  // (a concatenated input has two halves of EQUAL width, launcher-checked: one offset serves both sources)
+    int a_l[NA];
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         const int e = min(tid + k * NTH, A_F4 - 1);
         const int lp = e / (MS * (KC / 4)), rem = e % (MS * (KC / 4));
         const int row = rem / (KC / 4), c4 = (rem % (KC / 4)) * 4;
         const int sb = min(b0 + row, p.B - 1);
-        a_g1[k] = (sb * LLOAD + lp) * p.C1 + c4;
-        a_g2[k] = (sb * LLOAD + lp) * p.C2 + c4;
+        a_g1[k] = 4u * (unsigned)(((sb - b0) * LLOAD + lp) * p.C1 + c4);  // relative to the workgroup's first sample
         a_l[k] = lp * (MS * LDK) + row * LDK + c4;
     }
     // ---- weight fragment stream of this wave
-    const float* wb = p.W + ((size_t)(grp * S + s) * NKG) * (NSLAB * 256) + lane * 4;
+    // (uniform base; the lane's 16 bytes within a fragment are the 32-bit vector offset of the scalar-base load form)
+    const float* wb = p.W + ((size_t)(grp * S + s) * NKG) * (NSLAB * 256);
+    unsigned lane16 = 16u * lane;
+    // EDMP_OPAQUE keeps a 32-bit offset from being widened outside the K loop, where instruction selection would no longer
+    // see `uniform base + zext(offset)` and would fall back to 64-bit vector adds per load; EDMP_OPAQUE_S keeps a uniform
+    // byte offset in a scalar register, to be added to the scalar base (the immediate offset of a load reaches 4095 bytes)
+#define EDMP_OPAQUE(v) asm volatile("" : "+v"(v))
+#define EDMP_OPAQUE_S(v) asm volatile("" : "+s"(v))
+    auto refresh_offsets = [&]() __attribute__((always_inline)) {
+        EDMP_OPAQUE(lane16);
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            EDMP_OPAQUE(a_g1[k]);
+        }
+    };
+    // weight fragment j of a step: fragments come in runs of four per scalar base (4 x 1 KiB = the immediate range)
+    auto load_frag = [&](const float* w, auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        unsigned run = (j / 4) * 4096u;  // byte offset of the run, kept out of the load's immediate
+        if constexpr (j >= 4) EDMP_OPAQUE_S(run);
+        return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(w) + run + lane16 + (j % 4) * 1024);
+    };
 
     acc_t acc[LACC];
     acc_t racc[RES ? LLOAD : 1];
@@ -235,15 +262,16 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
     float rbias_v = 0.0f;
     if constexpr (RES) rbias_v = (ks == 0) ? p.res_bias[co0 + s * SW + (lane & (SW - 1))] : 0.0f;
 
-    f32x4 ra[NA];
+    f32x4 raA[NA], raB[NA];  // activation chunks in flight: fetched during one K step, committed to LDS during the next (two steps ahead: measured neutral)
     float4 bA[QW][NSLAB], bB[QW][NSLAB];
 
     auto load_a = [&](int nc, f32x4(&r)[NA]) __attribute__((always_inline)) {
         const bool first = nc < ch1;
-        const float* src = first ? p.src1 : p.src2;
-        const int ci0 = (first ? nc : nc - ch1) * KC;
+        const char* srcb = reinterpret_cast<const char*>((first ? p.src1 + (size_t)b0 * LLOAD * p.C1 : p.src2 + (size_t)b0 * LLOAD * p.C2) + (first ? nc : nc - ch1) * KC);
 #pragma unroll
-        for (int k = 0; k < NA; ++k) r[k] = *reinterpret_cast<const f32x4*>(src + (first ? a_g1[k] : a_g2[k]) + ci0);
+        for (int k = 0; k < NA; ++k) {
+            r[k] = *reinterpret_cast<const f32x4*>(srcb + a_g1[k]);
+        }
     };
     auto commit_a = [&](float* st, const f32x4(&r)[NA]) __attribute__((always_inline)) {
         if constexpr (BIL) {
@@ -270,27 +298,31 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
     };
     auto load_b = [&](int nc, float4(&b)[QW][NSLAB]) __attribute__((always_inline)) {
         const float* w = wb + ((size_t)(nc * (KC / KG) + ks * QW)) * (NSLAB * 256);
-#pragma unroll
-        for (int q = 0; q < QW; ++q)
-#pragma unroll
-            for (int t = 0; t < NSLAB; ++t) b[q][t] = *reinterpret_cast<const float4*>(w + (q * NSLAB + t) * 256);
+        refresh_offsets();
+        static_for<0, QW * NSLAB>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            b[j / NSLAB][j % NSLAB] = load_frag(w, jc);
+        });
     };
 
-    // ---- prologue: weights of chunk 0 in flight, activation chunk 0 staged (chunk 1 is fetched and committed by the first
-    //      K step, next to chunk 2: waiting for two chunks here cost 1-2.5 us of every launch at L >= 4)
+    // ---- prologue: weights of chunk 0 in flight, activation chunk 0 staged; chunks 1 and 2 are fetched and committed by the
+    //      first K step, next to the fetch of chunk 3 (waiting for them here cost 1-2.5 us of every launch at L >= 4)
+    f32x4 r1[NA];  // activation chunk 1 (the first step's extra staging set)
     load_b(0, bA);
-    load_a(0, ra);
-    commit_a(lds, ra);
+    load_a(0, raB);
+    commit_a(lds, raB);
     __syncthreads();
     EDMP_STAMP(0, 1)
 
     // A fragment of this lane: sample row lane % MS, channel quad lane / MS of the wave's K groups
     const int frag = (lane & (MS - 1)) * LDK + 4 * (lane / MS) + KG * QW * ks;
     float4 a4 = *reinterpret_cast<const float4*>(lds + frag);
-    float4 av[BIL ? L : 1];  // bilinear forms: the fragments of every staged position of the current K group
+    // bilinear forms: the fragments of every staged position of the current K group and (second set) of the next one,
+    // read a whole K group ahead
+    float4 av[2][BIL ? L : 1];
     if constexpr (BIL) {
 #pragma unroll
-        for (int v = 0; v < L; ++v) av[v] = *reinterpret_cast<const float4*>(lds + frag + v * (MS * LDK));
+        for (int v = 0; v < L; ++v) av[0][v] = *reinterpret_cast<const float4*>(lds + frag + v * (MS * LDK));
     }
 
     // one MFMA on component J of the current A fragment and of a weight fragment
@@ -301,27 +333,41 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
     // one K step: MFMAs of chunk i on stage `st` with fragments bc; fetch activation chunk i+2 and the weight fragments
     // of chunk i+1 (into bn); commit the fetched activations into stage `stw`; the first A fragment of chunk i+1 is read
     // from `stn` before the barrier.
-    f32x4 r1[NA];  // the first step's extra staging set (activation chunk 1)
-    auto step = [&](auto first_c, int i, const float* st, float* stn, float* stw, float4(&bc)[QW][NSLAB], float4(&bn)[QW][NSLAB]) __attribute__((always_inline)) {
-        constexpr bool FIRST = decltype(first_c)::value;  // step 0: also fetches chunk 1 and commits it into `stn`
-        const int nca = min(i + 2, nK - 1), ncb = min(i + 1, nK - 1);
+#ifdef EDMP_STAMPS
+    long long bar_cyc = 0;
+    const long long kl0 = clock64();
+#endif
+    // The stage ring position is a compile-time constant (the K loop below is unrolled over the 3 stages x 2 register
+    // sets), so every LDS address of a step is an invariant base register + immediate offset: no address arithmetic
+    // between the MFMAs.
+    auto step = [&](auto first_c, auto stage_c, auto par_c, int i, float4(&bc)[QW][NSLAB], float4(&bn)[QW][NSLAB], f32x4(&rc)[NA], f32x4(&rl)[NA]) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_c)::value;  // step 0: also commits chunk 1 (r1) into `stn`
+        constexpr int SG = decltype(stage_c)::value;      // stage holding chunk i; i+1 is in the next one, i+2 goes into the third
+        const float* st = lds + SG * A_FL;
+        float* stn = lds + ((SG + 1) % 3) * A_FL;
+        float* stw = lds + ((SG + 2) % 3) * A_FL;
+        constexpr int PAR = decltype(par_c)::value;       // bilinear forms: the av[] set that holds this step's first K group
+        // fetch chunk i+3 into `rl`, commit chunk i+2 (fetched during the previous step, in `rc`) into `stw`
+        const int nca = min(i + 3, nK - 1), ncb = min(i + 1, nK - 1);
         const bool first = nca < ch1;
-        const float* src = first ? p.src1 : p.src2;
-        const int ci0 = (first ? nca : nca - ch1) * KC;
+        const char* srcb = reinterpret_cast<const char*>((first ? p.src1 + (size_t)b0 * LLOAD * p.C1 : p.src2 + (size_t)b0 * LLOAD * p.C2) + (first ? nca : nca - ch1) * KC);
         const float* w = wb + ((size_t)(ncb * (KC / KG) + ks * QW)) * (NSLAB * 256);
-        // side work: the step's memory items (NA activation loads, NBL weight loads, NA commits of the staged chunk, in
-        // that order; the first step also carries chunk 1's loads and commits) are spread over SLOTS: one slot after
+        // first step: sources of chunks 1 and 2
+        const int nc1 = min(1, nK - 1), nc2 = min(2, nK - 1);
+        const bool first1 = nc1 < ch1, first2 = nc2 < ch1;
+        const char* srcb1 = reinterpret_cast<const char*>((first1 ? p.src1 + (size_t)b0 * LLOAD * p.C1 : p.src2 + (size_t)b0 * LLOAD * p.C2) + (first1 ? nc1 : nc1 - ch1) * KC);
+        const char* srcb2 = reinterpret_cast<const char*>((first2 ? p.src1 + (size_t)b0 * LLOAD * p.C1 : p.src2 + (size_t)b0 * LLOAD * p.C2) + (first2 ? nc2 : nc2 - ch1) * KC);
+        refresh_offsets();
+        // side work: the step's memory items (NBL weight loads, NA activation loads, the commits of the chunk fetched one
+        // step earlier, in that order; the first step also commits chunk 1) are spread over SLOTS: one slot after
         // each of the four component rounds of every MFMA block except the last block (whose shadow is too short for a
         // ds_write to complete before the step's barrier)
-        const bool first1 = 1 < ch1 || nK == 1;  // source of chunk 1 (FIRST)
-        const float* src1c = first1 ? p.src1 : p.src2;
-        const int ci1 = (nK == 1) ? 0 : (first1 ? KC : (1 - ch1) * KC);
         auto side = [&](auto xc) __attribute__((always_inline)) {
             constexpr int X = decltype(xc)::value;  // slot index
             constexpr int NSLOT = BIL ? Cf::NQSLOT : 4 * (NBLK - 1);
-            constexpr int NX = FIRST ? NA : 0;       // extra loads of the first step
-            constexpr int NXC = FIRST ? NCOMMIT : 0;  // ... and its extra commits
-            constexpr int NITEM = NA + NBL + NCOMMIT + NX + NXC;
+            constexpr int NX = FIRST ? 2 * NA : 0;    // extra fetches of the first step: chunks 1 (r1) and 2 (rc)
+            constexpr int NXC = FIRST ? NCOMMIT : 0;  // ... and its extra commits (chunk 1)
+            constexpr int NITEM = NX + NBL + NA + NXC + NCOMMIT;
             // commit item k of a staged chunk: k < NA the fetched positions, k == NA (Karatsuba form) position 2 = x0 + x1
             auto commit_item = [&](auto kc, float* stp, const f32x4(&r)[NA]) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
@@ -343,11 +389,18 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
             static_for<0, NITEM>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
                 if constexpr (j * NSLOT / NITEM == X) {
-                    if constexpr (j < NX) r1[j] = *reinterpret_cast<const f32x4*>(src1c + (first1 ? a_g1[j] : a_g2[j]) + ci1);
-                    else if constexpr (j < NX + NA) ra[j - NX] = *reinterpret_cast<const f32x4*>(src + (first ? a_g1[j - NX] : a_g2[j - NX]) + ci0);
-                    else if constexpr (j < NX + NA + NBL) bn[(j - NX - NA) / NSLAB][(j - NX - NA) % NSLAB] = *reinterpret_cast<const float4*>(w + (j - NX - NA) * 256);
-                    else if constexpr (j < NX + NA + NBL + NXC) commit_item(std::integral_constant<int, j - NX - NA - NBL>{}, stn, r1);
-                    else commit_item(std::integral_constant<int, j - NX - NA - NBL - NXC>{}, stw, ra);
+                    // (first step: chunks 1 and 2,) the weights of the next step (needed soonest), the activation fetch,
+                    // the commits
+                    if constexpr (j < NX) {
+                        constexpr int k = j % NA;
+                        if constexpr (j < NA) r1[k] = *reinterpret_cast<const f32x4*>(srcb1 + a_g1[k]);
+                        else rc[k] = *reinterpret_cast<const f32x4*>(srcb2 + a_g1[k]);
+                    } else if constexpr (j < NX + NBL) bn[(j - NX) / NSLAB][(j - NX) % NSLAB] = load_frag(w, std::integral_constant<int, j - NX>{});
+                    else if constexpr (j < NX + NBL + NA) {
+                        rl[j - NX - NBL] = *reinterpret_cast<const f32x4*>(srcb + a_g1[j - NX - NBL]);
+                    }
+                    else if constexpr (j < NX + NBL + NA + NXC) commit_item(std::integral_constant<int, j - NX - NBL - NA>{}, stn, r1);
+                    else commit_item(std::integral_constant<int, j - NX - NBL - NA - NXC>{}, stw, rc);
                 }
             });
         };
@@ -359,11 +412,12 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
             // position's fragment of the NEXT K group is read into place right after its last use (round w).
             static_for<0, QW>([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value;
+                constexpr int P = (PAR + q) & 1;
                 static_for<0, 4>([&](auto jc) __attribute__((always_inline)) {
                     constexpr int J = decltype(jc)::value;
                     static_for<0, L>([&](auto vc) __attribute__((always_inline)) {
                         constexpr int v = decltype(vc)::value;
-                        const float ax = (J == 0) ? av[v].x : (J == 1) ? av[v].y : (J == 2) ? av[v].z : av[v].w;
+                        const float ax = (J == 0) ? av[P][v].x : (J == 1) ? av[P][v].y : (J == 2) ? av[P][v].z : av[P][v].w;
                         static_for<0, LACC>([&](auto ac) __attribute__((always_inline)) {
                             constexpr int a = decltype(ac)::value;
                             if constexpr (Cf::slot(a, v) >= 0) {
@@ -377,9 +431,9 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
                             const float bx = (J == 0) ? bq.x : (J == 1) ? bq.y : (J == 2) ? bq.z : bq.w;
                             racc[Cf::rawpos(v) >= 0 ? Cf::rawpos(v) : 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bx, racc[Cf::rawpos(v) >= 0 ? Cf::rawpos(v) : 0], 0, 0, 0);
                         }
-                        if constexpr (J == 3 && !(FIRST && q + 1 == QW)) {
+                        if constexpr (J == 0 && !(FIRST && q + 1 == QW)) {  // the next K group's fragment of this position
                             const float* nx = (q + 1 < QW) ? st + frag + KG * (q + 1) : stn + frag;
-                            av[v] = *reinterpret_cast<const float4*>(nx + v * (MS * LDK));
+                            av[P ^ 1][v] = *reinterpret_cast<const float4*>(nx + v * (MS * LDK));
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         constexpr int X = (q * 4 + J) * L + v;
@@ -425,11 +479,17 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
                 });
             });
         }
+#ifdef EDMP_STAMPS
+        const long long tb0 = clock64();
         __syncthreads();
+        bar_cyc += clock64() - tb0;
+#else
+        __syncthreads();
+#endif
         if constexpr (FIRST) {
             if constexpr (BIL) {
 #pragma unroll
-                for (int v = 0; v < L; ++v) av[v] = *reinterpret_cast<const float4*>(stn + frag + v * (MS * LDK));
+                for (int v = 0; v < L; ++v) av[(PAR + QW) & 1][v] = *reinterpret_cast<const float4*>(stn + frag + v * (MS * LDK));
             } else {
                 a4 = *reinterpret_cast<const float4*>(stn + frag);
             }
@@ -437,21 +497,38 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
     };
 
     {
-        step(std::true_type{}, 0, lds, lds + A_FL, lds + 2 * A_FL, bA, bB);
-        int i = 1;
-        int sc = 1;  // stage of chunk i
-        for (; i + 1 < nK; i += 2) {
-            const int s1 = (sc == 2) ? 0 : sc + 1, s2 = (s1 == 2) ? 0 : s1 + 1;
-            step(std::false_type{}, i, lds + sc * A_FL, lds + s1 * A_FL, lds + s2 * A_FL, bB, bA);
-            step(std::false_type{}, i + 1, lds + s1 * A_FL, lds + s2 * A_FL, lds + sc * A_FL, bA, bB);
-            sc = s2;
-        }
-        if (i < nK) {
-            const int s1 = (sc == 2) ? 0 : sc + 1, s2 = (s1 == 2) ? 0 : s1 + 1;
-            step(std::false_type{}, i, lds + sc * A_FL, lds + s1 * A_FL, lds + s2 * A_FL, bB, bA);
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, QW & 1>;  // odd steps start on the other av[] set when a step has an odd number of K groups
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        using S2 = std::integral_constant<int, 2>;
+        const std::false_type F{};
+        step(std::true_type{}, S0{}, P0{}, 0, bA, bB, raA, raB);
+        // step i: stage i % 3; odd i on the second weight / activation register sets
+        for (int i = 1;;) {
+            if (i >= nK) break;
+            step(F, S1{}, P1{}, i++, bB, bA, raB, raA);
+            if (i >= nK) break;
+            step(F, S2{}, P0{}, i++, bA, bB, raA, raB);
+            if (i >= nK) break;
+            step(F, S0{}, P1{}, i++, bB, bA, raB, raA);
+            if (i >= nK) break;
+            step(F, S1{}, P0{}, i++, bA, bB, raA, raB);
+            if (i >= nK) break;
+            step(F, S2{}, P1{}, i++, bB, bA, raB, raA);
+            if (i >= nK) break;
+            step(F, S0{}, P0{}, i++, bA, bB, raA, raB);
         }
     }
 #undef EDMP_W_MFMA
+#undef EDMP_OPAQUE
+#undef EDMP_OPAQUE_S
+#ifdef EDMP_STAMPS
+    if (blockIdx.x == 0 && lane == 0) {
+        g_stamps[5][wave] = bar_cyc;
+        g_stamps[5][4 + wave] = clock64() - kl0;
+    }
+#endif
     EDMP_STAMP(0, 2)
 
     // ---- epilogue: K-slice partial tiles (+bias in slice 0) -> LDS; then per thread (sample row, column part) the
@@ -689,7 +766,7 @@ inline int xcd_split(int ng, int nt, double w_elems, double a_elems) {
 }
 
 template <int KIND, int MS, int CG, int GS, int LIN, bool RES>
-static int launch_wide_t(const RcbP& p, hipStream_t s) {
+int launch_wide_t(const RcbP& p, hipStream_t s) {
     static bool attr_set = false;
     constexpr size_t bytes = WideCfg<KIND, MS, CG, GS, LIN, RES>::lds_bytes();
     static_assert(bytes <= 160 * 1024, "position-tile conv kernel exceeds the 160 KiB LDS of a CU");
@@ -698,8 +775,14 @@ static int launch_wide_t(const RcbP& p, hipStream_t s) {
         attr_set = true;
     }
     const int ng = p.Cout / CG, nt = (p.B + MS - 1) / MS;
+    EDMP_REQUIRE(p.C2 == 0 || p.C2 == p.C1, "wide_conv_kernel: the two halves of a concatenated input must have the same width (C1=%d, C2=%d)", p.C1, p.C2);
     RcbP q = p;
-    q.gx = xcd_split(ng, nt, (double)p.Cout * (p.C1 + p.C2) * WideCfg<KIND, MS, CG, GS, LIN, RES>::NSLAB, (double)nt * MS * WideCfg<KIND, MS, CG, GS, LIN, RES>::LLOAD * (p.C1 + p.C2));
+    const int gx = xcd_split(ng, nt, (double)p.Cout * (p.C1 + p.C2) * WideCfg<KIND, MS, CG, GS, LIN, RES>::NSLAB, (double)nt * MS * WideCfg<KIND, MS, CG, GS, LIN, RES>::LLOAD * (p.C1 + p.C2));
+    q.gx_shift = q.ng_shift = -1;
+    if (gx > 0 && (ng & (ng - 1)) == 0) {
+        q.gx_shift = __builtin_ctz(gx);
+        q.ng_shift = __builtin_ctz(ng);
+    }
     hipLaunchKernelGGL((wide_conv_kernel<KIND, MS, CG, GS, LIN, RES>), dim3(ng * nt), dim3(256), bytes, s, q);
     return EDMP_OK;
 }

@@ -151,6 +151,7 @@ static void run_wide(int B, int C1, int C2, bool with_res_add) {
         hipMemcpyFromSymbol(st, HIP_SYMBOL(edmp::g_stamps), sizeof(st));
         printf("      stamps (shader cycles): prologue %llu | K loop %llu | spill %llu | stats+store %llu | total %llu cyc = %.2f us\n", st[0][2] - st[0][0],
                st[0][4] - st[0][2], st[0][6] - st[0][4], st[0][8] - st[0][6], st[0][8] - st[0][0], (st[0][9] - st[0][1]) / 100.0);
+        printf("      K loop per wave (cycles): %llu %llu %llu %llu | of which at the chunk barrier: %llu %llu %llu %llu\n", st[5][4], st[5][5], st[5][6], st[5][7], st[5][0], st[5][1], st[5][2], st[5][3]);
     }
 #endif
     for (float* q : {W, Wf, x1, x2, bias, gam, bet, tb, rb, res, d_old, d_new, r_old, r_new}) hipFree(q);
