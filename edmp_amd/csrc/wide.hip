@@ -125,7 +125,7 @@ struct WideCfg {
     static constexpr int NA = (A_F4 + NTH - 1) / NTH;
     static constexpr int NCOMMIT = BIL ? L : NA;        // ds_writes per thread per chunk (bilinear: one per STAGED position)
     static constexpr int NBL = QW * NSLAB;           // weight-fragment loads per wave per chunk
-    static constexpr int YS = LACC * CG + 4;
+    static constexpr int YS = LOUT * CG + 4;  // (bilinear forms combine their product tiles into output tiles in registers before the spill)
     static constexpr int NP = KSPLIT;                // partial tiles per output element
     static constexpr int PPR = NTH / MS;             // threads per sample row in the final pass
     static constexpr int ROW_F4 = LOUT * CG / 4;     // float4 per sample row
@@ -180,6 +180,10 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     EDMP_STAMP(0, 0)
+    // every launch parameter the prologue needs is pulled into scalar registers HERE, as one batch of s_loads: left to
+    // itself the compiler sinks the kernel-argument loads next to their first use behind the mapping branches - three
+    // dependent scalar-memory round trips in front of the first weight fetch
+    asm volatile("" ::"s"(p.src1), "s"(p.src2), "s"(p.W), "s"(p.bias), "s"(p.C1), "s"(p.C2), "s"(p.Cout), "s"(p.B), "s"(p.gx_shift), "s"(p.ng_shift));
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -582,10 +586,20 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
         }
         __syncthreads();
     }
+    // bilinear forms: output position l = sum of the product tiles in ocoef(l, .) - all in this wave's registers, in the
+    // same lane layout, so the combination costs a few VALU adds here instead of LDS traffic for every product tile
+    static_for<0, LOUT>([&](auto lc) __attribute__((always_inline)) {
+        constexpr int l = decltype(lc)::value;
 #pragma unroll
-    for (int l = 0; l < LACC; ++l)
-#pragma unroll
-        for (int r = 0; r < AR; ++r) Yw[acc_row(r) * YS + l * CG] = acc[l][r] + ((BIL && l > 0) ? 0.0f : bias_v);  // bilinear: the bias rides in accumulator 0, part of every output exactly once
+        for (int r = 0; r < AR; ++r) {
+            float y = bias_v;
+            static_for<0, LACC>([&](auto ac) __attribute__((always_inline)) {
+                constexpr int a = decltype(ac)::value;
+                if constexpr (Cf::ocoef(l, a)) y += acc[a][r];
+            });
+            Yw[acc_row(r) * YS + l * CG] = y;
+        }
+    });
     __syncthreads();
     EDMP_STAMP(0, 3)
     {
@@ -597,28 +611,7 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
             const int f = epart + PPR * i;
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((ROW_F4 % PPR == 0) || f < ROW_F4) {
-                if constexpr (BIL) {
-                    // output position l of channel quad c = sum of the accumulator tiles in ocoef(l, .); l is static per i
-                    // (a thread's i-th float4 lies 4 * PPR * i columns further)
-                    static_assert(4 * PPR <= CG && CG % (4 * PPR) == 0, "bilinear combine: output position static per item");
-                    const int c = (4 * f) % CG;
-                    static_for<0, LACC>([&](auto ac) __attribute__((always_inline)) {
-                        constexpr int a = decltype(ac)::value;
-                        static_for<0, NF4>([&](auto ic) __attribute__((always_inline)) {
-                            constexpr int ii = decltype(ic)::value;
-                            if (ii == i) {
-                                constexpr int lout = (4 * PPR * ii) / CG;
-                                if constexpr (lout < LOUT && Cf::ocoef(lout < LOUT ? lout : 0, a)) {
-#pragma unroll
-                                    for (int q = 0; q < NP; ++q) {
-                                        const float4 pv = *reinterpret_cast<const float4*>(Y + q * (MS * YS) + erow * YS + a * CG + c);
-                                        v[i].x += pv.x, v[i].y += pv.y, v[i].z += pv.z, v[i].w += pv.w;
-                                    }
-                                }
-                            }
-                        });
-                    });
-                } else {
+                {
                     v[i] = *reinterpret_cast<const float4*>(Y + erow * YS + 4 * f);
 #pragma unroll
                     for (int q = 1; q < NP; ++q) {
