@@ -99,6 +99,30 @@ __global__ __launch_bounds__(256) void level_kernel(LevelP p) {
 #pragma unroll
         for (int t = 0; t < 6; ++t) bf[t] = *reinterpret_cast<const float4*>(w + t * 256);
     }
+    // ---- level input staging.  With a wide input (the up levels: CIN = 128 / 256 concatenated channels, 51 KB per workgroup
+    //      that every XCD has to pull from HBM at the same moment) the tile is staged in NCH channel chunks: chunk 0 up
+    //      front, chunk c+1 requested before conv1's MFMAs on chunk c and committed behind them.
+    constexpr int NCH = (CIN >= 128) ? 4 : 1;            // input chunks
+    constexpr int QCH = (CIN / 4) / NCH;                 // float4 per input row per chunk
+    constexpr int NITC = (SB * L * QCH + 255) / 256;     // items per thread per chunk
+    static_assert((CIN / 4) % NCH == 0 && (NCH == 1 || (KX == CIN && (KX / 16) % NCH == 0)), "input chunks are whole K groups");
+    auto in_load = [&](int c, int it) __attribute__((always_inline)) {
+        const int i = min(tid + it * 256, SB * L * QCH - 1);
+        const int r = i / QCH, q = c * QCH + (i - r * QCH);
+        const int sb = r / L, l = r - sb * L;
+        const int bb = min(b0 + sb, p.B - 1);
+        const int c14 = p.C1 >> 2;
+        return (q < c14) ? *reinterpret_cast<const float4*>(p.src1 + ((size_t)bb * L + l) * p.C1 + 4 * q)
+                         : *reinterpret_cast<const float4*>(p.src2 + ((size_t)bb * L + l) * p.C2 + 4 * (q - c14));
+    };
+    auto in_commit = [&](int c, int it, const float4& v) __attribute__((always_inline)) {
+        const int i = tid + it * 256;
+        if (i < SB * L * QCH) {
+            const int r = i / QCH, q = c * QCH + (i - r * QCH);
+            const int sb = r / L, l = r - sb * L;
+            *reinterpret_cast<float4*>(TX + (sb * (L + 4) + l + 2) * RSX + 4 * q) = v;
+        }
+    };
     // ---- zero what the convolutions read but nobody writes: the 2 + 2 halo rows of every sample in the three tiles and
     //      the padded input channels (level 0: 8 stored channels in a 16-channel K group); then stage the level input
     {
@@ -113,37 +137,22 @@ __global__ __launch_bounds__(256) void level_kernel(LevelP p) {
             float* T = inx ? TX : (i - HX < HC ? TA : TB);
             *reinterpret_cast<float4*>(T + row * (inx ? RSX : RSC) + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const int c14 = p.C1 >> 2;
         constexpr int cq = CIN / 4;  // float4 per input row (C1 + C2 == CIN, checked by the launcher)
         if constexpr (4 * cq < KX)  // padded channels of the interior rows
             for (int i = tid; i < SB * L * (KX / 4 - cq); i += 256) {
                 const int r = i / (KX / 4 - cq), q = cq + i % (KX / 4 - cq);
                 *reinterpret_cast<float4*>(TX + ((r / L) * (L + 4) + r % L + 2) * RSX + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        // all loads of a batch are issued before the first LDS store: one memory round trip per batch, not per item
-        constexpr int NIT = (SB * L * (KX / 4) + 255) / 256, BATCH = 8;
-        const int total = SB * L * cq;
+        // the first input chunk (all of the input when it is staged in one piece): all loads of a batch are issued before the
+        // first LDS store - one memory round trip per batch, not per item
+        constexpr int NIT = (SB * L * QCH + 255) / 256, BATCH = 8;
 #pragma unroll 1
         for (int it0 = 0; it0 < NIT; it0 += BATCH) {
             float4 v[BATCH];
 #pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int i = min(tid + (it0 + u) * 256, total - 1);
-                const int r = i / cq, q = i - r * cq;
-                const int sb = r / L, l = r - sb * L;
-                const int bb = min(b0 + sb, p.B - 1);
-                v[u] = (q < c14) ? *reinterpret_cast<const float4*>(p.src1 + ((size_t)bb * L + l) * p.C1 + 4 * q)
-                                 : *reinterpret_cast<const float4*>(p.src2 + ((size_t)bb * L + l) * p.C2 + 4 * (q - c14));
-            }
+            for (int u = 0; u < BATCH; ++u) v[u] = in_load(0, it0 + u);
 #pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int i = tid + (it0 + u) * 256;
-                if (i < total) {
-                    const int r = i / cq, q = i - r * cq;
-                    const int sb = r / L, l = r - sb * L;
-                    *reinterpret_cast<float4*>(TX + (sb * (L + 4) + l + 2) * RSX + 4 * q) = v[u];
-                }
-            }
+            for (int u = 0; u < BATCH; ++u) in_commit(0, it0 + u, v[u]);
         }
     }
     __syncthreads();
@@ -164,14 +173,14 @@ __global__ __launch_bounds__(256) void level_kernel(LevelP p) {
 #pragma unroll
         for (int t = 0; t < NSLOT; ++t) b[t] = *reinterpret_cast<const float4*>(w + t * 256);
     };
-    auto conv_stage = [&](auto mtn_c, auto npair_c, auto nslot_c, auto mtsplit_c, auto pairs, const float* tile, int RS, int nkg, const float* wstream,
-                          const int(&ab)[MTMAX], const float4(&bfirst)[6]) __attribute__((always_inline)) {
+    auto conv_stage_range = [&](auto mtn_c, auto npair_c, auto nslot_c, auto mtsplit_c, auto pairs, const float* tile, int RS, int nkg, const float* wstream,
+                                const int(&ab)[MTMAX], float4(&bfirst)[6], int kg0, int kg1) __attribute__((always_inline)) {
         constexpr int MTN = decltype(mtn_c)::value, NPAIR = decltype(npair_c)::value, NSLOT = decltype(nslot_c)::value, MTSPLIT = decltype(mtsplit_c)::value;
         const float* w = wstream + ((size_t)s * nkg) * (NSLOT * 256) + lane * 4;
         float4 bcur[NSLOT], bnxt[NSLOT];
 #pragma unroll
         for (int t = 0; t < NSLOT; ++t) bcur[t] = bfirst[t];
-        for (int kg = 0; kg < nkg; ++kg) {
+        for (int kg = kg0; kg < kg1; ++kg) {
             const int kgn = min(kg + 1, nkg - 1);
 #pragma unroll
             for (int t = 0; t < NSLOT; ++t) bnxt[t] = *reinterpret_cast<const float4*>(w + ((size_t)kgn * NSLOT + t) * 256);
@@ -221,6 +230,12 @@ __global__ __launch_bounds__(256) void level_kernel(LevelP p) {
 #pragma unroll
             for (int t = 0; t < NSLOT; ++t) bcur[t] = bnxt[t];
         }
+#pragma unroll
+        for (int t = 0; t < NSLOT; ++t) bfirst[t] = bcur[t];  // a following range of the same stage continues with these
+    };
+    auto conv_stage = [&](auto mtn_c, auto npair_c, auto nslot_c, auto mtsplit_c, auto pairs, const float* tile, int RS, int nkg, const float* wstream,
+                          const int(&ab)[MTMAX], float4(&bfirst)[6]) __attribute__((always_inline)) {
+        conv_stage_range(mtn_c, npair_c, nslot_c, mtsplit_c, pairs, tile, RS, nkg, wstream, ab, bfirst, 0, nkg);
     };
 
     // A-row offsets of a stride-1 k5 stage over a tile with LL positions per sample and row stride RS
@@ -322,7 +337,25 @@ __global__ __launch_bounds__(256) void level_kernel(LevelP p) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) racc[m] = f4{0.f, 0.f, 0.f, 0.f};
     rows_k5(EDMP_IC(MT), L, RSX, ab);
-    conv_stage(EDMP_IC(MT), EDMP_IC(6), EDMP_IC(6), EDMP_IC(0), P_K5RES, TX, RSX, KX / 16, p.w11, ab, bf);
+    if constexpr (NCH == 1) {
+        conv_stage(EDMP_IC(MT), EDMP_IC(6), EDMP_IC(6), EDMP_IC(0), P_K5RES, TX, RSX, KX / 16, p.w11, ab, bf);
+    } else {
+        constexpr int KGC = (KX / 16) / NCH;  // K groups per input chunk
+        static_for<0, NCH>([&](auto cc) __attribute__((always_inline)) {
+            constexpr int c = decltype(cc)::value;
+            float4 v[NITC];
+            if constexpr (c + 1 < NCH) {
+#pragma unroll
+                for (int u = 0; u < NITC; ++u) v[u] = in_load(c + 1, u);
+            }
+            conv_stage_range(EDMP_IC(MT), EDMP_IC(6), EDMP_IC(6), EDMP_IC(0), P_K5RES, TX, RSX, KX / 16, p.w11, ab, bf, c * KGC, (c + 1) * KGC);
+            if constexpr (c + 1 < NCH) {
+#pragma unroll
+                for (int u = 0; u < NITC; ++u) in_commit(c + 1, u, v[u]);
+                __syncthreads();
+            }
+        });
+    }
     load_first(EDMP_IC(5), C / 16, p.w12, bf);
     EDMP_STAMP(LVSLOT, 2)
     {
