@@ -1,5 +1,5 @@
 // wide.hip — the "position-tile" convolution kernel of the UNet levels with >= 128 channels (round-2 design, weights
-// straight to registers).  Included by unet.hip.
+// straight to registers).
 //
 //   WK_K5   Conv1d(k=5, pad=2) + bias -> GroupNorm(8) -> Mish -> (+ time-bias | + residual) in ONE launch, optionally with
 //           the block's residual 1x1 conv folded in (reference: diffusion/models/blocks.py:22-28 Conv1dBlock, :162-164
@@ -27,8 +27,15 @@
 //   * only the activations go through LDS: [Lin][MS samples][KC + 4] per chunk in a ring of THREE stages, so chunk k+1
 //     is already visible while chunk k is consumed: the first A fragment of the next chunk is read BEFORE the step's
 //     barrier and no wave waits for LDS latency behind a barrier; one barrier per chunk.
-//   * the step's global loads (activation chunk k+2 -> staging registers, weight fragments of chunk k+1) and the
-//     ds_writes of the staged chunk are spread over the step, between the MFMA blocks of the input positions.
+//   * the step's global loads (weight fragments of chunk k+1, activation chunk k+3 -> staging registers) and the
+//     ds_writes of chunk k+2 (fetched during the previous step) are spread over the step, one item per slot after an MFMA
+//     round.
+//   * with one wave per SIMD every VALU instruction between two MFMAs delays the next MFMA's issue (measured: none of the
+//     K loop's loss was memory latency or the barrier), so the step contains no address arithmetic: loads take the
+//     scalar-base + constant 32-bit vector-offset form, the K loop is unrolled over the 3 ring stages x 2 register sets
+//     so that every LDS address is an invariant register + immediate, the workgroup mapping uses shifts and the kernel
+//     arguments are fetched as one scalar batch.
+// The including file includes this file only through unet.hip (single-unit builds) or kernel_shard.hip (sharded build).
 // grid = Cout / CG channel groups x ceil(B / MS) sample tiles, dealt to the 8 XCDs so that the sum of weight and activation
 // fetches over the 8 L2s is least (xcd_split).
 #pragma once
