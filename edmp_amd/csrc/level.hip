@@ -453,10 +453,54 @@ __global__ __launch_bounds__(256) void level_kernel(LevelP p) {
             __syncthreads();
             zero_acc();
             rows_k5(EDMP_IC(MTF), LOUT, RSC, ab);
+            // fused tail (below): this thread's state / noise values are requested before the conv stage, they land under it
+            double tail_x[8], tail_z[8];
+            const int tail_sm = tid / LOUT, tail_pos = tid - tail_sm * LOUT;
+            const bool tail_mine = (C == 32) && p.tail.on && tid < SB * LOUT && b0 + tail_sm < p.B;
+            if (tail_mine) tail_fetch(p.tail.X, p.tail.z, p.tail.rng != 0, b0 + tail_sm, tail_pos, LOUT, p.tail.C, tail_x, tail_z);
+            // ... and the head's weights go into LDS behind the output tile (224 wave-uniform scalar loads in a row would
+            // serialise on the scalar cache): TA / TB are dead since the barrier above
+            float* TW = TA + SB * LOUT * RSC;
+            if constexpr (C == 32) {
+                static_assert(SB * LOUT * RSC + 8 * C + 8 <= 2 * Cf::TC_FL, "head weights fit behind the output tile");
+                if (p.tail.on) {
+                    for (int i = tid; i < p.tail.C * C; i += 256) TW[i] = p.tail.w[i];
+                    if (tid < 8) TW[8 * C + tid] = tid < p.tail.C ? p.tail.bias[tid] : 0.0f;
+                }
+            }
             conv_stage(EDMP_IC(MTF), EDMP_IC(5), EDMP_IC(5), EDMP_IC(0), P_K5, TF, RSC, C / 16, p.wfin, ab, bf);
-            gn_epilogue(EDMP_IC(MTF), EDMP_IC(LOUT), p.bfin, p.gfin, p.befin, no_add, [&](int, int, int sm, int pos, float y) __attribute__((always_inline)) {
-                if (b0 + sm < p.B) p.out[((size_t)(b0 + sm) * LOUT + pos) * C + col] = y;
-            });
+            if (!p.tail.on) {
+                gn_epilogue(EDMP_IC(MTF), EDMP_IC(LOUT), p.bfin, p.gfin, p.befin, no_add, [&](int, int, int sm, int pos, float y) __attribute__((always_inline)) {
+                    if (b0 + sm < p.B) p.out[((size_t)(b0 + sm) * LOUT + pos) * C + col] = y;
+                });
+            } else {
+                // device-resident loop: the UNet's output activation never leaves the CU.  It goes into the (dead) TA/TB tiles
+                // as [sample][position][C + 4]; then one thread per (sample, waypoint) runs the tail of the reverse step -
+                // final 1x1 conv, posterior step, conditioning, next UNet input (tail.h; the same code head_psample_kernel runs)
+                if constexpr (C == 32) {
+                    static_assert(SB * LOUT * RSC <= 2 * Cf::TC_FL && SB * LOUT <= 256, "the output tile fits the two dead activation tiles, one thread per row");
+                    float* TY = TA;
+                    gn_epilogue(EDMP_IC(MTF), EDMP_IC(LOUT), p.bfin, p.gfin, p.befin, no_add,
+                                [&](int, int, int sm, int pos, float y) __attribute__((always_inline)) { TY[(sm * LOUT + pos) * RSC + col] = y; });
+                    __syncthreads();
+                    if (tail_mine) {
+                        float4 hv[C / 4];
+#pragma unroll
+                        for (int q = 0; q < C / 4; ++q) hv[q] = *reinterpret_cast<const float4*>(TY + tid * RSC + 4 * q);
+                        const TailP& tl = p.tail;
+                        const int b = b0 + tail_sm, pos = tail_pos, i = b * LOUT + pos;
+#define EDMP_TAIL(FIN, RN) head_psample_item<FIN, RN, C>(hv, tail_x, tail_z, i, b, pos, TW, TW + 8 * C, tl.X, nullptr, tl.xin, tl.sg, LOUT, tl.C, tl.c1, tl.sqrt_alpha, tl.beta, tl.zero_row0, tl.seed, tl.rng_step, tl.cond)
+                        if (tl.finish) {
+                            if (tl.rng) EDMP_TAIL(true, true);
+                            else EDMP_TAIL(true, false);
+                        } else {
+                            if (tl.rng) EDMP_TAIL(false, true);
+                            else EDMP_TAIL(false, false);
+                        }
+#undef EDMP_TAIL
+                    }
+                }
+            }
         }
     }
     EDMP_STAMP(LVSLOT, 7)

@@ -2,6 +2,7 @@
 // shared by the core translation unit and the kernel shards (kernel_shard.hip).
 #pragma once
 #include "common.h"
+#include "tail.h"
 
 namespace edmp {
 
@@ -90,6 +91,7 @@ struct LevelP {
     float* skip_out;  // [B][L][C] output of the second block (the level's skip tensor), or nullptr
     float* out;       // [B][LOUT][C] (LV_UP_FINAL: the final Conv1dBlock's output at the up-sampled length)
     int B;
+    TailP tail;       // LV_UP_FINAL in the device-resident loop: head 1x1 conv + posterior step on the tile still in LDS (tail.h)
 };
 
 #ifdef EDMP_STAMPS  // phase timing experiment (scratch builds only): one wave of one mid-grid workgroup stamps s_memtime

@@ -5,6 +5,7 @@
 // State X is float64 on device exactly like the reference's NumPy state; the UNet sees float32(X), eps (f32) is
 // promoted to f64 in the posterior; the noise stream z is an input (host NumPy RNG order is part of the contract).
 #include "common.h"
+#include "tail.h"
 
 namespace edmp {
 
@@ -20,7 +21,7 @@ void set_error(const char* fmt, ...) {
 
 // unet.hip / guide.hip
 int unet_forward_impl(edmp_ctx* ctx, const float* x_dev, int B, int t, float* eps_dev);
-int unet_run_program(edmp_ctx* ctx, int B, int t);
+int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_done);
 int guide_raw_gradient_from_X(edmp_ctx* ctx, const double* X_dev, int B, int N, int t);
 int guide_set_startgoal(edmp_ctx* ctx, const double* start, const double* goal);
 int guide_prepare(edmp_ctx* ctx, int B, int L);
@@ -126,51 +127,6 @@ __global__ void condition_kernel(double* __restrict__ X, int B, int C, int N, co
     X[(size_t)i * N + N - 1] = sg[7 + c];
 }
 
-// ---- device noise source (NOT the reference's NumPy stream: a separate, explicitly non-parity mode) --------------------
-// Philox4x32-10 counter RNG (Salmon et al. 2011): counter = (element, step, block, 0), key = seed.  Eight standard
-// normals per (sample, waypoint) and step via Box-Muller, one per joint channel.  Removes the 0.9 s host draw and the
-// 734 MB upload per scene that the NumPy-stream contract costs.
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        const uint32_t n3 = (uint32_t)p0;
-        c0 = n0;
-        c1 = n1;
-        c2 = n2;
-        c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    out[0] = c0;
-    out[1] = c1;
-    out[2] = c2;
-    out[3] = c3;
-}
-
-__device__ __forceinline__ void rng_normal8(uint64_t seed, uint32_t step, uint32_t elem, float (&z)[8]) {
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        uint32_t u[4];
-        philox4x32_10(elem, step, (uint32_t)blk, 0u, k0, k1, u);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float u1 = ((float)u[2 * h] + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]
-            const float u2 = (float)u[2 * h + 1] * 2.3283064365386963e-10f;       // [0, 1)
-            const float r = sqrtf(-2.0f * logf(u1));
-            float sn, cs;
-            sincospif(2.0f * u2, &sn, &cs);
-            z[4 * blk + 2 * h] = r * cs;
-            z[4 * blk + 2 * h + 1] = r * sn;
-        }
-    }
-}
-
 // the z tensor (B,C,N) f64 the loop uses at `step` (0 = initial state, 1 + T - t = reverse step t): tests / inspection
 __global__ void rng_normal_kernel(uint64_t seed, int step, double* __restrict__ out, int B, int C, int N) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -226,6 +182,25 @@ __global__ __launch_bounds__(256) void head_psample_kernel(const float* __restri
                                                            float* __restrict__ xin, const double* __restrict__ sg, int B, int N, int Cin, int C,
                                                            double c1, double sqrt_alpha, double beta, int zero_row0, uint64_t seed, int rng_step, int cond) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if constexpr (CIN > 0) {  // compile-time width: all input loads are issued back to back; the shared tail does the rest
+        // the head's weights through LDS (224 wave-uniform scalar loads in a row serialise on the scalar cache)
+        __shared__ float sw[8 * (CIN > 0 ? CIN : 4) + 8];
+        for (int k = threadIdx.x; k < C * CIN; k += blockDim.x) sw[k] = w[k];
+        if (threadIdx.x < 8) sw[8 * CIN + threadIdx.x] = (int)threadIdx.x < C ? bias[threadIdx.x] : 0.0f;
+        const bool mine = i < B * N;
+        const int ii = mine ? i : 0;
+        const int b = ii / N, l = ii - b * N;
+        const float* hp = h + (size_t)ii * Cin;
+        float4 hv[CIN / 4];
+        double xv[8], zv[8];
+#pragma unroll
+        for (int q = 0; q < CIN / 4; ++q) hv[q] = *reinterpret_cast<const float4*>(hp + 4 * q);
+        tail_fetch(X, z, RNG, b, l, N, C, xv, zv);
+        __syncthreads();
+        if (mine)
+            head_psample_item<FINISH, RNG, (CIN > 0 ? CIN : 4)>(hv, xv, zv, i, b, l, sw, sw + 8 * CIN, X, eps_out, xin, sg, N, C, c1, sqrt_alpha, beta, zero_row0, seed, rng_step, cond);
+        return;
+    }
     if (i >= B * N) return;
     const int b = i / N, l = i - b * N;
     const float* hp = h + (size_t)i * Cin;
@@ -236,24 +211,7 @@ __global__ __launch_bounds__(256) void head_psample_kernel(const float* __restri
     float acc[8];
 #pragma unroll
     for (int co = 0; co < 8; ++co) acc[co] = (co < C) ? bias[co] : 0.0f;
-    if constexpr (CIN > 0) {  // compile-time width: all input loads are issued back to back, then the FMAs
-        float4 hv[CIN / 4];
-#pragma unroll
-        for (int q = 0; q < CIN / 4; ++q) hv[q] = *reinterpret_cast<const float4*>(hp + 4 * q);
-#pragma unroll
-        for (int q = 0; q < CIN / 4; ++q) {
-#pragma unroll
-            for (int co = 0; co < 8; ++co) {
-                if (co < C) {
-                    const float* wr = w + co * CIN + 4 * q;
-                    acc[co] = fmaf(hv[q].x, wr[0], acc[co]);
-                    acc[co] = fmaf(hv[q].y, wr[1], acc[co]);
-                    acc[co] = fmaf(hv[q].z, wr[2], acc[co]);
-                    acc[co] = fmaf(hv[q].w, wr[3], acc[co]);
-                }
-            }
-        }
-    } else {
+    {  // run-time width (architectures whose head input is neither 16 nor 32 channels wide)
         for (int c4 = 0; c4 < Cin; c4 += 4) {
             const float4 hv = *reinterpret_cast<const float4*>(hp + c4);
 #pragma unroll
@@ -346,11 +304,33 @@ static int step_a(edmp_ctx* ctx, double* X, const double* z, int B, int t, int z
     hipStream_t st = ctx->stream;
     const dim3 grid_bn((B * N + 255) / 256);
     if (!fused) hipLaunchKernelGGL(pack_state_kernel, grid_bn, dim3(256), 0, st, X, u->x_in, B, C, N);
-    int rc = unet_run_program(ctx, B, t);
-    if (rc) return rc;
     const bool g = guided && guided_step(t);
     const int zr = (zero_row0 && t == 1) ? 1 : 0;
     const int rstep = 1 + (s->T - t);
+    // device-resident loop: the step's tail (final 1x1 conv, posterior, conditioning, next input) rides in the UNet's last
+    // launch when the architecture ends in the fused final level (tail.h); the teacher-forced API keeps the separate launch
+    TailP tail;
+    bool tail_done = false;
+    const bool want_tail = fused && !eps_out && !xpost_out;
+    if (want_tail) {
+        tail.X = X;
+        tail.z = z;
+        tail.xin = g ? nullptr : u->x_in;
+        tail.sg = s->sg;
+        tail.C = C;
+        tail.N = N;
+        tail.c1 = s->c1[t - 1];
+        tail.sqrt_alpha = s->sqrt_alpha[t - 1];
+        tail.beta = s->beta[t - 1];
+        tail.zero_row0 = zr;
+        tail.seed = seed;
+        tail.rng_step = rstep;
+        tail.cond = s->condition;
+        tail.finish = g ? 0 : 1;
+        tail.rng = use_rng ? 1 : 0;
+    }
+    int rc = unet_run_program(ctx, B, t, want_tail ? &tail : nullptr, &tail_done);
+    if (rc) return rc;
 #define EDMP_HP_ARGS(xin_ptr) u->h_last, u->head_w, u->head_b, X, z, eps_out, (xin_ptr), s->sg, B, N, u->head_cin, C, s->c1[t - 1], s->sqrt_alpha[t - 1], s->beta[t - 1], zr, seed, rstep, s->condition
 #define EDMP_HP_LAUNCH(FIN, RN, xin_ptr)                                                                                              \
     {                                                                                                                                  \
@@ -358,7 +338,8 @@ static int step_a(edmp_ctx* ctx, double* X, const double* z, int B, int t, int z
         else if (u->head_cin == 16) hipLaunchKernelGGL((head_psample_kernel<FIN, RN, 16>), grid_bn, dim3(256), 0, st, EDMP_HP_ARGS(xin_ptr)); \
         else hipLaunchKernelGGL((head_psample_kernel<FIN, RN, 0>), grid_bn, dim3(256), 0, st, EDMP_HP_ARGS(xin_ptr));                        \
     }
-    if (fused && !g) {
+    if (tail_done) {
+    } else if (fused && !g) {
         if (use_rng) EDMP_HP_LAUNCH(true, true, u->x_in)
         else EDMP_HP_LAUNCH(true, false, u->x_in)
     } else {

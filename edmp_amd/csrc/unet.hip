@@ -1216,6 +1216,10 @@ static bool karatsuba_l2() {
     return on;
 }
 // ... and the L = 4 convolutions of the 256/512-channel levels in the nested form (9 instead of 14 products; WK_K5K4)
+static bool fuse_tail() {  // EDMP_NO_FUSED_TAIL=1: the step's tail stays its own launch (ablation / A-B)
+    static const bool on = !getenv("EDMP_NO_FUSED_TAIL");
+    return on;
+}
 static bool karatsuba_l4() {
     static const bool on = getenv("EDMP_NO_KARATSUBA") == nullptr && getenv("EDMP_NO_KARATSUBA4") == nullptr;
     return on;
@@ -2180,7 +2184,10 @@ extern "C" int edmp_unet_read_packed(edmp_ctx* ctx, float* out_host, int64_t cap
 namespace edmp {
 // shared with sampler.hip: run the forward on the context's stream
 // run the layer program on u->x_in ([B][N][8], already filled); leaves the head input in u->h_last
-int unet_run_program(edmp_ctx* ctx, int B, int t) {
+// `tail` (device-resident loop): if the program ends with the fused final level (LV_UP_FINAL, 32 channels into the head) the
+// tail of the reverse step runs inside that launch and *tail_done is set; otherwise the caller launches head_psample_kernel
+int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_done) {
+    if (tail_done) *tail_done = false;
     UNet* u = ctx->unet;
     EDMP_REQUIRE(u, "edmp_unet_load has not been called");
     EDMP_REQUIRE(B >= 1 && B <= u->max_batch, "batch %d outside 1..max_batch=%d", B, u->max_batch);
@@ -2241,6 +2248,13 @@ int unet_run_program(edmp_ctx* ctx, int B, int t) {
             p.B = B;
             p.tb1 = trow + op.lv_tb1;
             p.tb2 = trow + op.lv_tb2;
+            if (tail && tail_done && op.lv_variant == 4 && op_index + 1 == (int)u->prog.size() && u->head_cin == 32 && tail->N == u->desc.horizon && tail->C <= 8 && p.out == u->h_last && fuse_tail()) {
+                p.tail = *tail;
+                p.tail.on = 1;
+                p.tail.w = u->head_w;
+                p.tail.bias = u->head_b;
+                *tail_done = true;
+            }
             rc = launch_level(p, op.lv_variant, s);
         } else if (op.kind == OP_WRS) {
             RcbP p = op.rc;
@@ -2307,7 +2321,7 @@ int unet_forward_impl(edmp_ctx* ctx, const float* x_dev, int B, int t, float* ep
         int total = B * N * 8;
         hipLaunchKernelGGL(pack_input_kernel, dim3((total + 255) / 256), dim3(256), 0, s, x_dev, u->x_in, B, C, N, 8);
     }
-    int rc = unet_run_program(ctx, B, t);
+    int rc = unet_run_program(ctx, B, t, nullptr, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(head_1x1_kernel, dim3((B * N + 255) / 256), dim3(256), 0, s, u->h_last, u->head_w, u->head_b, eps_dev, B, N,
                        u->head_cin, C);
