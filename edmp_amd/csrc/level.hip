@@ -469,21 +469,35 @@ __global__ __launch_bounds__(256) void level_kernel(LevelP p) {
                 }
             }
             conv_stage(EDMP_IC(MTF), EDMP_IC(5), EDMP_IC(5), EDMP_IC(0), P_K5, TF, RSC, C / 16, p.wfin, ab, bf);
-            if (!p.tail.on) {
-                gn_epilogue(EDMP_IC(MTF), EDMP_IC(LOUT), p.bfin, p.gfin, p.befin, no_add, [&](int, int, int sm, int pos, float y) __attribute__((always_inline)) {
-                    if (b0 + sm < p.B) p.out[((size_t)(b0 + sm) * LOUT + pos) * C + col] = y;
-                });
-            } else {
-                // device-resident loop: the UNet's output activation never leaves the CU.  It goes into the (dead) TA/TB tiles
-                // as [sample][position][C + 4]; then one thread per (sample, waypoint) runs the tail of the reverse step -
+            {
+                // ONE instance of the epilogue arithmetic for both destinations (two instances may be contracted differently by
+                // the compiler: the loop and the stepwise API would then differ in the last ulp).
+                // Device-resident loop (tail.on): the UNet's output activation never leaves the CU.  It goes into the (dead) TA/TB
+                // tiles as [sample][position][C + 4]; then one thread per (sample, waypoint) runs the tail of the reverse step -
                 // final 1x1 conv, posterior step, conditioning, next UNet input (tail.h; the same code head_psample_kernel runs)
+                float* TY = TA;
+                const bool to_lds = (C == 32) && p.tail.on;
+                float yv[MTF * 4];
+                int yrow[MTF * 4];  // (sample within the workgroup) * LOUT + position, -1: padding row
+#pragma unroll
+                for (int e = 0; e < MTF * 4; ++e) yrow[e] = -1;
+                gn_epilogue(EDMP_IC(MTF), EDMP_IC(LOUT), p.bfin, p.gfin, p.befin, no_add, [&](int m, int r, int sm, int pos, float y) __attribute__((always_inline)) {
+                    yv[m * 4 + r] = y;  // (m, r are compile-time constants at every call site: registers, not scratch)
+                    yrow[m * 4 + r] = sm * LOUT + pos;
+                });
+                if (to_lds) {
+#pragma unroll
+                    for (int e = 0; e < MTF * 4; ++e)
+                        if (yrow[e] >= 0) TY[yrow[e] * RSC + col] = yv[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < MTF * 4; ++e)
+                        if (yrow[e] >= 0 && b0 + yrow[e] / LOUT < p.B) p.out[((size_t)b0 * LOUT + yrow[e]) * C + col] = yv[e];
+                }
                 if constexpr (C == 32) {
                     static_assert(SB * LOUT * RSC <= 2 * Cf::TC_FL && SB * LOUT <= 256, "the output tile fits the two dead activation tiles, one thread per row");
-                    float* TY = TA;
-                    gn_epilogue(EDMP_IC(MTF), EDMP_IC(LOUT), p.bfin, p.gfin, p.befin, no_add,
-                                [&](int, int, int sm, int pos, float y) __attribute__((always_inline)) { TY[(sm * LOUT + pos) * RSC + col] = y; });
-                    __syncthreads();
-                    if (tail_mine) {
+                    if (to_lds) __syncthreads();  // (uniform)
+                    if (to_lds && tail_mine) {
                         float4 hv[C / 4];
 #pragma unroll
                         for (int q = 0; q < C / 4; ++q) hv[q] = *reinterpret_cast<const float4*>(TY + tid * RSC + 4 * q);

@@ -548,6 +548,34 @@ def test_full_size_properties():
     assert np.array_equal(e_all[300:400], e_sub)
 
 
+def test_device_loop_equals_the_stepwise_api_at_full_size():
+    """The device-resident loop runs the tail of a reverse step (final 1x1 conv, posterior, conditioning, next input)
+    inside the UNet's last launch (level kernel, tail.h); the stepwise API runs it as its own launch.  Same code, same
+    operands: the state after 6 steps (3 guided) must be bit-identical, rows of a ragged last workgroup included."""
+    from edmp_amd import scenes
+    from edmp_amd.diffusion import Diffusion
+    from edmp_amd.guide import IntersectionVolumeGuide
+    from edmp_amd.guide_cfg import split_rows
+    from edmp_amd.temporalunet import TemporalUNet
+
+    B = 37  # not a multiple of the level kernel's 4-sample workgroups
+    net = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, seed=2, max_batch=64)
+    guides = [1, 10, 11]
+    cfgs = cfgs_for(guides, 0, rows_per_guide=split_rows(B, len(guides)))
+    scene = scenes.random_scene(5, 12)
+    guide = IntersectionVolumeGuide(scene, DEV, cfgs, B)
+    dif = Diffusion(T, DEV)
+    noise = np.random.RandomState(8).standard_normal((T + 1, B, 7, 50))
+    s, gl = scenes.DEFAULT_START, scenes.DEFAULT_GOAL
+    n = 6
+    X_loop = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=s, goal=gl, noise=noise, t_stop=T - n)
+    X = noise[0].copy()
+    X[:, :, 0], X[:, :, -1] = s, gl
+    for k, t in enumerate(range(T, T - n, -1)):
+        X = dif.denoise_step(net, guide, X, noise[1 + k], t, s, gl, cfgs["guidance_schedule"])["x_out"]
+    assert np.array_equal(X_loop, X), (float(np.abs(X_loop - X).max()), int((X_loop != X).sum()), np.argwhere(X_loop != X)[:5].tolist())
+
+
 def test_infer_serial_driver_c1():
     """BASELINE configs[0] plumbing: guides [1], 4 rows, one scene, through the reference-shaped driver."""
     import os
