@@ -137,6 +137,19 @@ __device__ __forceinline__ float swap32_add(float x) {
     return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
 }
 
+// two elements at once: the non-transcendental half of the formula on packed-fp32 instructions (v_pk_mul/add/fma_f32: two
+// lanes' worth of work per issue slot); per component the same operations in the same order as mish_fast
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t mish_fast2(f32x2_t x) {
+    f32x2_t xm = {fminf(x.x, 20.0f), fminf(x.y, 20.0f)};
+    xm = xm * 1.44269504088896340736f;
+    const f32x2_t n = {__builtin_amdgcn_exp2f(xm.x), __builtin_amdgcn_exp2f(xm.y)};
+    const f32x2_t w = n * (n + 2.0f);
+    const f32x2_t d = w + 2.0f;
+    const f32x2_t rc = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    return x * (w * rc);
+}
+
 // x * tanh(softplus(x)) with torch's softplus threshold (20): blocks.py:27,65 -> torch.nn.Mish
 __device__ __forceinline__ float mish_f(float x) {
     float sp = (x > 20.0f) ? x : log1pf(expf(x));

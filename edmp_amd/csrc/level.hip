@@ -294,20 +294,30 @@ __global__ __launch_bounds__(256) void level_kernel(LevelP p) {
 #pragma unroll
         for (int b = 0; b < SBW; ++b) rstd[b] = 1.0f / sqrtf(lv_group_sum<GS>(part[b]) * inv_n + 1e-5f);
         rstd[SBW] = 0.f;
-        static_for<0, MTN * 4>([&](auto ec) __attribute__((always_inline)) {
-            constexpr int m = decltype(ec)::value / 4, r = decltype(ec)::value % 4;
-            constexpr int blo = (16 * m + r) / LL < SBW ? (16 * m + r) / LL : SBW, bhi = (16 * m + r + 12) / LL < SBW ? (16 * m + r + 12) / LL : SBW;
-            if constexpr (blo < SBW) {
+        // normalise + Mish two elements at a time (rows r, r + 1 of a tile: same channel; packed-fp32 instructions for all but
+        // min / exp2 / rcp), each element with its own sample's statistics
+        static_for<0, MTN * 2>([&](auto ec) __attribute__((always_inline)) {
+            constexpr int m = decltype(ec)::value / 2, r0 = 2 * (decltype(ec)::value % 2);
+            float sc2[2], sh2[2];
+            int sm2[2], pos2[2];
+            bool ok2[2];
+            static_for<0, 2>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value, r = r0 + j;
+                constexpr int blo = (16 * m + r) / LL < SBW ? (16 * m + r) / LL : SBW, bhi = (16 * m + r + 12) / LL < SBW ? (16 * m + r + 12) / LL : SBW;
                 const int rho = 16 * m + r + rq4;
                 const bool hi = (blo != bhi) && rho >= bhi * LL;
-                const int sm = hi ? bhi : blo;
-                const int pos = rho - sm * LL;
+                sm2[j] = hi ? bhi : blo;
+                pos2[j] = rho - sm2[j] * LL;
                 const float mu = hi ? mean[bhi] : mean[blo], rs = hi ? rstd[bhi] : rstd[blo];
-                if (bhi < SBW || !hi) {  // not a padding row
-                    const float sc = rs * gv;
-                    const float y = mish_fast(acc[m][r] * sc + (bev - sc * mu)) + addend(m, r, hs + sm, pos);
-                    emit(m, r, hs + sm, pos, y);
-                }
+                sc2[j] = rs * gv;
+                sh2[j] = bev - sc2[j] * mu;
+                ok2[j] = (blo < SBW) && (bhi < SBW || !hi);  // not a padding row
+            });
+            constexpr int blo0 = (16 * m + r0) / LL < SBW ? (16 * m + r0) / LL : SBW;
+            if constexpr (blo0 < SBW) {  // (a pair whose first row lies behind the last sample is padding altogether)
+                const f32x2_t y2 = mish_fast2(f32x2_t{acc[m][r0], acc[m][r0 + 1]} * f32x2_t{sc2[0], sc2[1]} + f32x2_t{sh2[0], sh2[1]});
+                if (ok2[0]) emit(m, r0, hs + sm2[0], pos2[0], y2.x + addend(m, r0, hs + sm2[0], pos2[0]));
+                if (ok2[1]) emit(m, r0 + 1, hs + sm2[1], pos2[1], y2.y + addend(m, r0 + 1, hs + sm2[1], pos2[1]));
             }
         });
     };

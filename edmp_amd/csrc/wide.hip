@@ -660,10 +660,11 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
                         const int l = col / CG, ch = co0 + col % CG;
                         const float s0 = rstd * g4[i].x, s1 = rstd * g4[i].y, s2 = rstd * g4[i].z, s3 = rstd * g4[i].w;
                         float4 o;
-                        o.x = mish_fast(v[i].x * s0 + (be4[i].x - s0 * mean)) + ad4[i].x;
-                        o.y = mish_fast(v[i].y * s1 + (be4[i].y - s1 * mean)) + ad4[i].y;
-                        o.z = mish_fast(v[i].z * s2 + (be4[i].z - s2 * mean)) + ad4[i].z;
-                        o.w = mish_fast(v[i].w * s3 + (be4[i].w - s3 * mean)) + ad4[i].w;
+                        // (packed fp32: two elements per instruction for everything but min / exp2 / rcp)
+                        const f32x2_t sa = {s0, s1}, sb = {s2, s3};
+                        const f32x2_t ya = mish_fast2(f32x2_t{v[i].x, v[i].y} * sa + (f32x2_t{be4[i].x, be4[i].y} - sa * mean)) + f32x2_t{ad4[i].x, ad4[i].y};
+                        const f32x2_t yb = mish_fast2(f32x2_t{v[i].z, v[i].w} * sb + (f32x2_t{be4[i].z, be4[i].w} - sb * mean)) + f32x2_t{ad4[i].z, ad4[i].w};
+                        o.x = ya.x, o.y = ya.y, o.z = yb.x, o.w = yb.y;
                         *reinterpret_cast<float4*>(p.dst + ((size_t)b * LOUT + l) * p.Cout + ch) = o;
                     }
                 }
