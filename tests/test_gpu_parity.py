@@ -574,6 +574,13 @@ def test_device_loop_equals_the_stepwise_api_at_full_size():
     for k, t in enumerate(range(T, T - n, -1)):
         X = dif.denoise_step(net, guide, X, noise[1 + k], t, s, gl, cfgs["guidance_schedule"])["x_out"]
     assert np.array_equal(X_loop, X), (float(np.abs(X_loop - X).max()), int((X_loop != X).sum()), np.argwhere(X_loop != X)[:5].tolist())
+    # the same with the device noise source (Philox inside the fused tail) against the materialised stream
+    Xd = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=s, goal=gl, noise="device", seed=77, t_stop=T - n)
+    stream = np.zeros((T + 1, B, 7, 50))
+    for k in range(n + 1):
+        stream[k] = dif.device_noise(77, k, B)
+    Xs = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=s, goal=gl, noise=stream, t_stop=T - n)
+    assert np.array_equal(Xd, Xs)
 
 
 def test_infer_serial_driver_c1():
