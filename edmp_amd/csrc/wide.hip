@@ -319,8 +319,8 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
     // ---- prologue: weights of chunk 0 in flight, activation chunk 0 staged; chunks 1 and 2 are fetched and committed by the
     //      first K step, next to the fetch of chunk 3 (waiting for them here cost 1-2.5 us of every launch at L >= 4)
     f32x4 r1[NA];  // activation chunk 1 (the first step's extra staging set)
-    load_b(0, bA);
-    load_a(0, raB);
+    load_a(0, raB);  // first: its data is on the way to the first MFMA twice (commit, barrier, fragment read) ...
+    load_b(0, bA);   // ... the weights only once, and memory returns in request order
     commit_a(lds, raB);
     __syncthreads();
     EDMP_STAMP(0, 1)
