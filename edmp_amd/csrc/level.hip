@@ -94,11 +94,6 @@ __global__ __launch_bounds__(256) void level_kernel(LevelP p) {
 
     EDMP_STAMP(LVSLOT, 0)
     float4 bf[6];  // weight fragments of the next stage's first K group, requested one stage early
-    {  // ... those of RCB 1's conv1 right away: they land while the input tile is staged
-        const float* w = p.w11 + ((size_t)s * (KX / 16)) * (6 * 256) + lane * 4;
-#pragma unroll
-        for (int t = 0; t < 6; ++t) bf[t] = *reinterpret_cast<const float4*>(w + t * 256);
-    }
     // ---- level input staging.  With a wide input (the up levels: CIN = 128 / 256 concatenated channels, 51 KB per workgroup
     //      that every XCD has to pull from HBM at the same moment) the tile is staged in NCH channel chunks: chunk 0 up
     //      front, chunk c+1 requested before conv1's MFMAs on chunk c and committed behind them.
@@ -123,6 +118,17 @@ __global__ __launch_bounds__(256) void level_kernel(LevelP p) {
             *reinterpret_cast<float4*>(TX + (sb * (L + 4) + l + 2) * RSX + 4 * q) = v;
         }
     };
+    // the first input chunk (all of the input when it is staged in one piece) is requested FIRST - it is what the first MFMA
+    // waits for, and memory returns in request order - then RCB 1's first weight fragments; both land while the halos are zeroed
+    constexpr int NIT = (SB * L * QCH + 255) / 256;
+    float4 vin[NIT];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) vin[u] = in_load(0, u);
+    {
+        const float* w = p.w11 + ((size_t)s * (KX / 16)) * (6 * 256) + lane * 4;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) bf[t] = *reinterpret_cast<const float4*>(w + t * 256);
+    }
     // ---- zero what the convolutions read but nobody writes: the 2 + 2 halo rows of every sample in the three tiles and
     //      the padded input channels (level 0: 8 stored channels in a 16-channel K group); then stage the level input
     {
@@ -143,17 +149,8 @@ __global__ __launch_bounds__(256) void level_kernel(LevelP p) {
                 const int r = i / (KX / 4 - cq), q = cq + i % (KX / 4 - cq);
                 *reinterpret_cast<float4*>(TX + ((r / L) * (L + 4) + r % L + 2) * RSX + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        // the first input chunk (all of the input when it is staged in one piece): all loads of a batch are issued before the
-        // first LDS store - one memory round trip per batch, not per item
-        constexpr int NIT = (SB * L * QCH + 255) / 256, BATCH = 8;
-#pragma unroll 1
-        for (int it0 = 0; it0 < NIT; it0 += BATCH) {
-            float4 v[BATCH];
 #pragma unroll
-            for (int u = 0; u < BATCH; ++u) v[u] = in_load(0, it0 + u);
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) in_commit(0, it0 + u, v[u]);
-        }
+        for (int u = 0; u < NIT; ++u) in_commit(0, u, vin[u]);
     }
     __syncthreads();
 
