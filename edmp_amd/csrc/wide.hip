@@ -174,8 +174,14 @@ struct WideAcc<16> {
 };
 
 // weight-fragment stream of one conv in HBM: [Cout/SW][Cin/KG][NSLAB][64 lanes][4] floats (pack_fragments)
+// The parameters every workgroup needs before it can request its first bytes are leading scalar kernel arguments: with
+// -mllvm -amdgpu-kernarg-preload-count=12 the command processor delivers them in SGPRs at wave launch, no scalar-memory round
+// trip in front of the first loads (the struct `pr` carries the rest; its copies of these fields are ignored)
 template <int KIND, int MS, int CG, int GS, int LIN, bool RES>
-__global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
+__global__ __launch_bounds__(256) void wide_conv_kernel(const float* a_src1, const float* a_src2, const float* a_W, int a_C1, int a_C2, int a_Cout, int a_B,
+                                                        int a_gx_shift, int a_ng_shift, RcbP pr) {
+    RcbP p = pr;
+    p.src1 = a_src1, p.src2 = a_src2, p.W = a_W, p.C1 = a_C1, p.C2 = a_C2, p.Cout = a_Cout, p.B = a_B, p.gx_shift = a_gx_shift, p.ng_shift = a_ng_shift;
     using Cf = WideCfg<KIND, MS, CG, GS, LIN, RES>;
     using acc_t = typename WideAcc<MS>::type;
     constexpr int L = Cf::L, LLOAD = Cf::LLOAD, LOUT = Cf::LOUT, LACC = Cf::LACC, SW = Cf::SW, KG = Cf::KG, AR = Cf::AR;
@@ -187,10 +193,6 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     EDMP_STAMP(0, 0)
-    // every launch parameter the prologue needs is pulled into scalar registers HERE, as one batch of s_loads: left to
-    // itself the compiler sinks the kernel-argument loads next to their first use behind the mapping branches - three
-    // dependent scalar-memory round trips in front of the first weight fetch
-    asm volatile("" ::"s"(p.src1), "s"(p.src2), "s"(p.W), "s"(p.bias), "s"(p.C1), "s"(p.C2), "s"(p.Cout), "s"(p.B), "s"(p.gx_shift), "s"(p.ng_shift));
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -268,10 +270,6 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
 #pragma unroll
             for (int i = 0; i < AR; ++i) racc[t][i] = 0.0f;
     }
-    // epilogue operands requested up front (they land long before they are used)
-    const float bias_v = (ks == 0) ? p.bias[co0 + s * SW + (lane & (SW - 1))] : 0.0f;
-    float rbias_v = 0.0f;
-    if constexpr (RES) rbias_v = (ks == 0) ? p.res_bias[co0 + s * SW + (lane & (SW - 1))] : 0.0f;
 
     f32x4 raA[NA], raB[NA];  // activation chunks in flight: fetched during one K step, committed to LDS during the next (two steps ahead: measured neutral)
     float4 bA[QW][NSLAB], bB[QW][NSLAB];
@@ -321,6 +319,11 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(RcbP p) {
     f32x4 r1[NA];  // activation chunk 1 (the first step's extra staging set)
     load_a(0, raB);  // first: its data is on the way to the first MFMA twice (commit, barrier, fragment read) ...
     load_b(0, bA);   // ... the weights only once, and memory returns in request order
+    // epilogue operands requested now (they land long before they are used; their pointers are not among the preloaded
+    // kernel arguments, so anything earlier would put a scalar-memory wait in front of the loads above)
+    const float bias_v = (ks == 0) ? p.bias[co0 + s * SW + (lane & (SW - 1))] : 0.0f;
+    float rbias_v = 0.0f;
+    if constexpr (RES) rbias_v = (ks == 0) ? p.res_bias[co0 + s * SW + (lane & (SW - 1))] : 0.0f;
     commit_a(lds, raB);
     __syncthreads();
     EDMP_STAMP(0, 1)
@@ -784,7 +787,7 @@ int launch_wide_t(const RcbP& p, hipStream_t s) {
         q.gx_shift = __builtin_ctz(gx);
         q.ng_shift = __builtin_ctz(ng);
     }
-    hipLaunchKernelGGL((wide_conv_kernel<KIND, MS, CG, GS, LIN, RES>), dim3(ng * nt), dim3(256), bytes, s, q);
+    hipLaunchKernelGGL((wide_conv_kernel<KIND, MS, CG, GS, LIN, RES>), dim3(ng * nt), dim3(256), bytes, s, q.src1, q.src2, q.W, q.C1, q.C2, q.Cout, q.B, q.gx_shift, q.ng_shift, q);
     return EDMP_OK;
 }
 
