@@ -68,7 +68,10 @@ __device__ __forceinline__ float lv_group_sum(float x) {
 }
 
 template <int MODE, int C, int L, int SB, int CIN>
-__global__ __launch_bounds__(256) void level_kernel(LevelP p) {
+__global__ __launch_bounds__(256) void level_kernel(const float* a_src1, const float* a_src2, const float* a_w11, int a_C1, int a_C2, int a_B, LevelP pr) {
+    // (leading scalar arguments = what the input staging needs: preloaded into SGPRs at wave launch, see wide_conv_kernel)
+    LevelP p = pr;
+    p.src1 = a_src1, p.src2 = a_src2, p.w11 = a_w11, p.C1 = a_C1, p.C2 = a_C2, p.B = a_B;
     using Cf = LevelCfg<MODE, C, L, SB, CIN>;
     constexpr int KX = Cf::KX;
     constexpr int NSLABW = Cf::NSLABW, SBW = Cf::SBW, GS = Cf::GS, MT = Cf::MT, MTMAX = Cf::MTMAX, LOUT = Cf::LOUT;
@@ -538,7 +541,7 @@ int launch_level_t(const LevelP& p, hipStream_t s) {
         EDMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&level_kernel<MODE, C, L, SB, CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((level_kernel<MODE, C, L, SB, CIN>), dim3((p.B + SB - 1) / SB), dim3(256), bytes, s, p);
+    hipLaunchKernelGGL((level_kernel<MODE, C, L, SB, CIN>), dim3((p.B + SB - 1) / SB), dim3(256), bytes, s, p.src1, p.src2, p.w11, p.C1, p.C2, p.B, p);
     return EDMP_OK;
 }
 
