@@ -150,6 +150,14 @@ __device__ __forceinline__ f32x2_t mish_fast2(f32x2_t x) {
     return x * (w * rc);
 }
 
+// a + b on both halves in ONE instruction.  Plain `a + b` on two-element vectors that were extracted from a float4 and go back
+// into one is split into scalar adds by the compiler; inside the conv K loop every VALU instruction costs an MFMA issue slot
+__device__ __forceinline__ f32x2_t pk_add(f32x2_t a, f32x2_t b) {
+    f32x2_t r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // x * tanh(softplus(x)) with torch's softplus threshold (20): blocks.py:27,65 -> torch.nn.Mish
 __device__ __forceinline__ float mish_f(float x) {
     float sp = (x > 20.0f) ? x : log1pf(expf(x));

@@ -288,16 +288,19 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(const float* a_src1, con
             // (sample row, channel quad)
             static_for<0, L>([&](auto vc) __attribute__((always_inline)) {
                 constexpr int v = decltype(vc)::value;
-                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                // (two packed-fp32 adds per sum: every VALU instruction in the K step costs an MFMA issue slot)
+                f32x2_t slo = {0.f, 0.f}, shi = {0.f, 0.f};
                 bool have = false;
                 static_for<0, LLOAD>([&](auto lc) __attribute__((always_inline)) {
                     constexpr int lp = decltype(lc)::value;
                     if constexpr (Cf::vcoef(v, lp)) {
-                        sum = have ? sum + r[lp] : r[lp];
+                        const f32x2_t rlo = {r[lp].x, r[lp].y}, rhi = {r[lp].z, r[lp].w};
+                        slo = have ? pk_add(slo, rlo) : rlo;
+                        shi = have ? pk_add(shi, rhi) : rhi;
                         have = true;
                     }
                 });
-                *reinterpret_cast<f32x4*>(st + a_l[0] + v * (MS * LDK)) = sum;
+                *reinterpret_cast<f32x4*>(st + a_l[0] + v * (MS * LDK)) = f32x4{slo.x, slo.y, shi.x, shi.y};
             });
         } else {
 #pragma unroll
@@ -386,16 +389,18 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(const float* a_src1, con
             auto commit_item = [&](auto kc, float* stp, const f32x4(&r)[NA]) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
                 if constexpr (BIL) {  // staged position k = sum of the fetched positions in vcoef(k, .)
-                    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                    f32x2_t slo = {0.f, 0.f}, shi = {0.f, 0.f};
                     bool have = false;
                     static_for<0, LLOAD>([&](auto lc) __attribute__((always_inline)) {
                         constexpr int lp = decltype(lc)::value;
                         if constexpr (Cf::vcoef(k, lp)) {
-                            sum = have ? sum + r[lp] : r[lp];
+                            const f32x2_t rlo = {r[lp].x, r[lp].y}, rhi = {r[lp].z, r[lp].w};
+                            slo = have ? pk_add(slo, rlo) : rlo;
+                            shi = have ? pk_add(shi, rhi) : rhi;
                             have = true;
                         }
                     });
-                    *reinterpret_cast<f32x4*>(stp + a_l[0] + k * (MS * LDK)) = sum;
+                    *reinterpret_cast<f32x4*>(stp + a_l[0] + k * (MS * LDK)) = f32x4{slo.x, slo.y, shi.x, shi.y};
                 } else {
                     if ((A_F4 % NTH == 0) || tid + k * NTH < A_F4) *reinterpret_cast<f32x4*>(stp + a_l[k]) = r[k];
                 }
