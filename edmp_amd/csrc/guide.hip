@@ -172,23 +172,28 @@ __global__ __launch_bounds__(256) void guide_kernel(GuideArgs<TIn> a, RobotConst
     // this lane's joint vector: padded waypoint w = lane (0 start, 1..L interior, >= L+1 goal)
     const int w = lane;
     float q[7];
+    {
+        // all seven joint values are requested before any of them is looked at (per-joint branches would serialise seven
+        // round trips to a state the previous kernel has just written), lanes outside 1..L read a clamped waypoint and
+        // take start / goal instead
+        const int wi = min(max(w - 1, 0), L - 1);
+        TIn xr[7];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        float v;
-        if (w == 0) v = a.startgoal[j];
-        else if (w > L) v = a.startgoal[7 + j];
-        else {
-            TIn x = a.joints[((size_t)rr * 7 + j) * a.ldw + a.off + (w - 1)];
+        for (int j = 0; j < 7; ++j) xr[j] = a.joints[((size_t)rr * 7 + j) * a.ldw + a.off + wi];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            float v;
             if (a.do_clip) {
-                double xd = (double)x;
+                double xd = (double)xr[j];
                 xd = xd < rc.qlo[j] ? rc.qlo[j] : xd;
                 xd = xd > rc.qhi[j] ? rc.qhi[j] : xd;
                 v = (float)xd;
             } else {
-                v = (float)x;
+                v = (float)xr[j];
             }
+            const float vs = a.startgoal[j], vg = a.startgoal[7 + j];
+            q[j] = (w == 0) ? vs : ((w > L) ? vg : v);
         }
-        q[j] = v;
     }
     const bool interior = (w >= 1) && (w <= L);
     const bool seg_ok = (w <= L);  // segment (w, w+1)
