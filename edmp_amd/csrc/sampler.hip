@@ -339,6 +339,7 @@ static int step_a(edmp_ctx* ctx, double* X, const double* z, int B, int t, int z
         else hipLaunchKernelGGL((head_psample_kernel<FIN, RN, 0>), grid_bn, dim3(256), 0, st, EDMP_HP_ARGS(xin_ptr));                        \
     }
     if (tail_done) {
+        // the UNet's last launch has already run the tail of this step
     } else if (fused && !g) {
         if (use_rng) EDMP_HP_LAUNCH(true, true, u->x_in)
         else EDMP_HP_LAUNCH(true, false, u->x_in)
