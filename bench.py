@@ -41,9 +41,9 @@ def effective_cores() -> int:
 
 
 def pmc_traffic():
-    """HBM MB per conv-family launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_hbm_traffic.json, else
-    round 1's; produced by scripts/pmc_unet_forward.py + scripts/summarize_pmc.py).  Counters cannot be read live."""
-    for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+    """HBM MB per conv-family launch from the committed rocprofv3 PMC passes (profiles/r03_pmc_hbm_traffic.json, else
+    an earlier round's; produced by scripts/pmc_unet_forward.py + scripts/summarize_pmc.py).  Counters cannot be read live."""
+    for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)["conv_family"]
@@ -133,9 +133,12 @@ def main():
         X = dif.denoise_guided(net, guide, N, C, cfgs["guidance_schedule"], batch_size=B, start=start, goal=goal, noise=noise, return_device=True,
                                allreduce=ar, zero_row0=(rank == 0 or not logical))
         vols, idx = guide.row_swept_volumes(start, goal, X)  # synchronises (argmin comes back to the host)
+        # plan success of EVERY row (exact link-box vs obstacle check, csrc/success.hip): the second half of the metric
+        sr = guide.success_rows(X)
         traj = X[idx].cpu().numpy()
-        ok = ED.geometric_success(float(vols[idx]), traj)
-        return ED.gather_best(float(vols[idx]), idx, traj, ok, device=dev)
+        res = ED.gather_best(float(vols[idx]), idx, traj, bool(sr["ok"][idx]), device=dev, rows_ok=sr["rows_ok"], rows=sr["rows"])
+        res["aabb_volume_zero"] = ED.geometric_success(float(vols[idx]), traj)  # the guide's own (conservative) criterion, rank-local
+        return res
 
     def barrier():
         torch.cuda.synchronize()
@@ -179,8 +182,12 @@ def main():
                 "parallelism": (f"one logical batch of {world * B} rows row-sharded x{world}: RCCL all-reduce of sum(g^2) per guided step inside the device loop + end-of-sampling gather"
                                 if logical else (f"row-sharded replicas x{world}, end-of-sampling RCCL gather" if world > 1 else "single GPU")),
             },
-            "best": {"rank": best["rank"], "row": best["index"], "swept_volume": best["volume"], "geometric_success_proxy": best["success"],
-                     "note": "random-init denoiser: the proxy (zero t=0 swept AABB volume + joint limits) is expected to be false; reported, never gated"},
+            "best": {"rank": best["rank"], "row": best["index"], "swept_volume": best["volume"], "aabb_volume_zero_and_within_limits": best["aabb_volume_zero"]},
+            "success_proxy": {"rows_ok": best["rows_ok"], "rows": best["rows"], "rate": best["rows_ok"] / max(best["rows"], 1), "best_row_ok": best["success"],
+                              "note": "plan success-rate half of the metric, computed INSIDE the timed call for every row of the batch (summed over ranks): all waypoints "
+                                      "within the joint limits and no link box meeting an obstacle (exact oriented-box / cylinder test, 4 interpolated configurations per "
+                                      "segment) - a geometric stand-in for the reference's pybullet check (lib/environment.py:632-680), which is unavailable offline; "
+                                      "random-init denoiser (no trained weights offline): the rate says nothing about planning quality, it is reported, never gated"},
             "unet_flops_per_traj_step": {"nominal": nominal, "direct_form_after_tap_skipping": net.flops_direct_form(), "issued_mfma": executed, "survey": SURVEY_FLOPS_PER_TRAJ_STEP,
                                          "note": "issued < direct form: the L=2 / L=4 Conv1dBlocks run in Karatsuba form (3 of 4 resp. 9 of 14 matrix products)"},
         }
@@ -253,7 +260,7 @@ def main():
         avg_s = 1e-3 * conv_ms / max(launches, 1)
         out["roofline"] = {
             "kernel": "fp32-MFMA conv family of the TemporalUNet: edmp::wide_conv_kernel (position-tile Conv1d k5 + GroupNorm + Mish, k3s2, ConvTranspose k4s2; "
-                      "128..512 channels) + edmp::rcb_block_kernel / rcb_rows_kernel / conv_mfma_kernel (32/64-channel levels)",
+                      "128..512 channels) + edmp::level_kernel (whole 32/64-channel levels: two residual blocks + resampling conv per launch)",
             "bound": "mfma",
             "achieved": ach,
             "peak": PEAK_F32_MFMA_TFLOPS,

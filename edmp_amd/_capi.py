@@ -51,6 +51,8 @@ SIGNATURES = {
     "edmp_guide_swept_cost_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _pf, _pf, _vp]),
     "edmp_guide_gradient_dev": (_i, [_vp, _vp, _i, _i, _pd, _pd, _i, _vp, _vp]),
     "edmp_row_swept_volumes_dev": (_i, [_vp, _vp, _i, _i, _pd, _pd, _vp, C.POINTER(_i)]),
+    "edmp_scene_set_shapes": (_i, [_vp, _pi32, _i]),
+    "edmp_success_rows_dev": (_i, [_vp, _vp, _i, _i, _i, _pd, _vp, _vp, _vp, _pi32]),
     "edmp_sampler_init": (_i, [_vp, _i, _d]),
     "edmp_sampler_read_schedule": (_i, [_vp, _pd, _pd, _pd]),
     "edmp_sampler_set_condition": (_i, [_vp, _i]),

@@ -88,6 +88,8 @@ struct edmp_ctx {
 namespace edmp {
 
 void unet_destroy(UNet*);
+bool unet_complete(const UNet*);   // loaded: has a layer program
+bool guide_complete(const Guide*);  // scene tables and row arrays both set
 int prof_fold(edmp_ctx* ctx);  // unet.hip: read the pending event pairs into the per-op / total accumulators
 void guide_destroy(Guide*);
 void sampler_destroy(Sampler*);

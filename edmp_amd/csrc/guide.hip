@@ -13,40 +13,17 @@
 //     corner of every AABB face, with torch's sub-gradient conventions: first index on corner ties
 //     (torch.min/max(dim)), half/half on elementwise min/max ties, clamp(min=0) passes gradient at len >= 0.
 #include "common.h"
+#include "guide.h"
 
 namespace edmp {
 
-struct RobotConst {
-    float dh[7][4];      // a, d, cos(alpha), sin(alpha)
-    float sf[9][12];     // static frames, row-major 3x4
-    float he[9][3];      // link half extents
-    double qlo[7], qhi[7];
-};
 
-struct Guide {
-    int no = 0, G = 0, T = 0;
-    float* aabb = nullptr;  // [G][T+1][no][6]
-    RobotConst rc{};
-    // rows
-    int B = 0;
-    int32_t* row_class = nullptr;
-    float* method = nullptr;
-    double* grad_norm = nullptr;
-    double* sched = nullptr;  // [B][T]
-    int rows_T = 0;
-    // scratch
-    float* graw = nullptr;    // [B][7][L] raw f32 gradient
-    double* rowsq = nullptr;  // [B]
-    double* sumsq = nullptr;  // [1]
-    float* startgoal = nullptr;  // [14] f32
-    int scratch_B = 0, scratch_L = 0;
-    float* vol_rows = nullptr;  // [B] for best trajectory
-};
+bool guide_complete(const Guide* g) { return g && g->aabb && g->obb && g->row_class; }
 
 void guide_destroy(Guide* g) {
     if (!g) return;
     for (void* p : {(void*)g->aabb, (void*)g->row_class, (void*)g->method, (void*)g->grad_norm, (void*)g->sched, (void*)g->graw,
-                    (void*)g->rowsq, (void*)g->sumsq, (void*)g->startgoal, (void*)g->vol_rows})
+                    (void*)g->rowsq, (void*)g->sumsq, (void*)g->startgoal, (void*)g->vol_rows, (void*)g->obb, (void*)g->kind, (void*)g->flags})
         if (p) (void)hipFree(p);
     delete g;
 }
@@ -572,9 +549,9 @@ extern "C" int edmp_scene_set(edmp_ctx* ctx, const double* obstacle_config, int 
         EDMP_HIP_CHECK(hipMemsetAsync(ctx->guide->startgoal, 0, 14 * sizeof(float), ctx->stream));
     }
     Guide* g = ctx->guide;
-    if (g->aabb) {
-        (void)hipFree(g->aabb);
-        g->aabb = nullptr;
+    for (void** p : {(void**)&g->aabb, (void**)&g->obb, (void**)&g->kind}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
     }
     g->no = no;
     g->G = G;
@@ -589,18 +566,27 @@ extern "C" int edmp_scene_set(edmp_ctx* ctx, const double* obstacle_config, int 
         g->rc.qlo[i] = lo_deg[i] * (pi / 180);  // diffusion.py:282-296 evaluates deg*(np.pi/180)
         g->rc.qhi[i] = hi_deg[i] * (pi / 180);
     }
-    std::vector<double> sizes(no * 3);
+    std::vector<double> sizes(no * 3), obb((size_t)no * 16, 0.0);
     std::vector<float> tf(no * 12);
     for (int o = 0; o < no; ++o) {
         const double* c = obstacle_config + o * 10;
         double m[3][3];
         quat_to_matrix(c + 3, m);
         for (int k = 0; k < 3; ++k) {
-            for (int j = 0; j < 3; ++j) tf[o * 12 + k * 4 + j] = (float)m[k][j];
+            for (int j = 0; j < 3; ++j) {
+                tf[o * 12 + k * 4 + j] = (float)m[k][j];
+                obb[o * 16 + k * 3 + j] = m[k][j];
+            }
             tf[o * 12 + k * 4 + 3] = (float)c[k];
             sizes[o * 3 + k] = c[7 + k];
+            obb[o * 16 + 9 + k] = c[k];
+            obb[o * 16 + 12 + k] = c[7 + k] / 2;  // the simulator's half extents (lib/environment.py:235)
         }
     }
+    EDMP_HIP_CHECK(hipMalloc((void**)&g->obb, obb.size() * sizeof(double)));
+    EDMP_HIP_CHECK(hipMalloc((void**)&g->kind, no * sizeof(int32_t)));
+    EDMP_HIP_CHECK(hipMemcpy(g->obb, obb.data(), obb.size() * sizeof(double), hipMemcpyHostToDevice));
+    EDMP_HIP_CHECK(hipMemset(g->kind, 0, no * sizeof(int32_t)));  // every obstacle a cuboid until edmp_scene_set_shapes says otherwise
     double *d_sizes = nullptr, *d_clr = nullptr, *d_exp = nullptr;
     float* d_tf = nullptr;
     EDMP_HIP_CHECK(hipMalloc((void**)&d_sizes, sizes.size() * sizeof(double)));

@@ -432,10 +432,20 @@ extern "C" void edmp_ctx_destroy(edmp_ctx* ctx) {
 }
 
 // make slot `key` the current one: park the current object (most recently used first), fetch the slot if resident
-template <class T, class D>
-static int select_slot(std::vector<std::pair<uint64_t, T*>>& slots, T*& cur, uint64_t& cur_key, uint64_t key, int cap, D destroy) {
-    if (key == cur_key) return cur ? 1 : 0;
-    if (cur) slots.insert(slots.begin(), {cur_key, cur});
+// Returns 1 only for a COMPLETE object: one whose load failed half way (edmp_scene_set after its `new Guide`, a UNet without a
+// layer program) is destroyed and reported as an empty slot, so the caller loads into it again.
+template <class T, class D, class C>
+static int select_slot(std::vector<std::pair<uint64_t, T*>>& slots, T*& cur, uint64_t& cur_key, uint64_t key, int cap, D destroy, C complete) {
+    auto usable = [&]() {
+        if (cur && !complete(cur)) {
+            destroy(cur);
+            cur = nullptr;
+        }
+        return cur ? 1 : 0;
+    };
+    if (key == cur_key) return usable();
+    if (cur && complete(cur)) slots.insert(slots.begin(), {cur_key, cur});
+    else if (cur) destroy(cur);
     cur = nullptr;
     cur_key = key;
     for (size_t i = 0; i < slots.size(); ++i)
@@ -448,21 +458,21 @@ static int select_slot(std::vector<std::pair<uint64_t, T*>>& slots, T*& cur, uin
         destroy(slots.back().second);
         slots.pop_back();
     }
-    return cur ? 1 : 0;
+    return usable();
 }
 
 extern "C" int edmp_unet_slot(edmp_ctx* ctx, uint64_t key) {
     if (!ctx) return EDMP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return EDMP_ERR_HIP;
     ctx->epoch++;
-    return select_slot(ctx->unet_slots, ctx->unet, ctx->unet_key, key, ctx->unet_cap, unet_destroy);
+    return select_slot(ctx->unet_slots, ctx->unet, ctx->unet_key, key, ctx->unet_cap, unet_destroy, unet_complete);
 }
 
 extern "C" int edmp_guide_slot(edmp_ctx* ctx, uint64_t key) {
     if (!ctx) return EDMP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return EDMP_ERR_HIP;
     ctx->epoch++;
-    return select_slot(ctx->guide_slots, ctx->guide, ctx->guide_key, key, ctx->guide_cap, guide_destroy);
+    return select_slot(ctx->guide_slots, ctx->guide, ctx->guide_key, key, ctx->guide_cap, guide_destroy, guide_complete);
 }
 
 extern "C" int edmp_ctx_set_stream(edmp_ctx* ctx, void* hip_stream) {

@@ -1403,6 +1403,8 @@ static void op_kernel_name(const Op& op, char* out) {
     }
 }
 
+bool unet_complete(const UNet* u) { return u && u->wpack && u->tbias && !u->prog.empty(); }
+
 void unet_destroy(UNet* u) {
     if (!u) return;
     if (u->wpack) (void)hipFree(u->wpack);

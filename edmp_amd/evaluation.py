@@ -1,12 +1,15 @@
-"""Result evaluation on the host (NumPy): geometric success check and trajectory metrics.
+"""Result evaluation: plan success over the whole batch (on the GPU) and trajectory metrics (host, like the reference's).
 
-The reference scores a plan by executing it in pybullet (`RobotEnvironment.benchmark_trajectory`,
-lib/environment.py:632-680: position control through the waypoints, contact query `check_collisions` :591-608) and
-has path-length / SPARC helpers in lib/metrics.py:11-125 (never called by the driver).  pybullet is not available
-offline, so the success criterion is restated geometrically — EXACT oriented-box tests instead of the guide's
-conservative world-AABB overlap: the 9 Franka link boxes (lib/guide.py:243-342) against every obstacle box at every
-waypoint and at `substeps` interpolated configurations per segment (pybullet's controller sweeps the same joint-space
-segment).  This is a proxy (no dynamics, box-shaped links), reported as such; it is not on the GPU hot path.
+Success.  The reference scores a plan by executing it in pybullet (`RobotEnvironment.benchmark_trajectory`,
+lib/environment.py:632-680: position control through the waypoints, contact query `check_collisions` :591-608 against
+spawned cuboids AND true cylinders :230-268) and tallies `t_success` (infer_serial.py:94-99,165-168).  pybullet is not
+available offline, so the criterion is restated geometrically — EXACT oriented-box / finite-cylinder tests instead of the
+guide's conservative world-AABB overlap — and evaluated for every row of the batch by `edmp_success_rows_dev`
+(csrc/success.hip) through `IntersectionVolumeGuide.success_rows`.  It is a stand-in (no dynamics, box-shaped links),
+reported as such.  There is no host fallback: the checker of the kernel lives in oracle/success_oracle.py (tests only).
+
+Metrics.  lib/metrics.py:11-125 (`MetricsCalculator`, host NumPy / torch-CPU in the reference too, never called by its
+driver): path length and SPARC smoothness, pinned to the reference by tests/golden/g13_metrics.npz.
 """
 from __future__ import annotations
 
@@ -20,85 +23,22 @@ def _dh(a, d, alpha, q):
     return np.array([[cq, -sq, 0, a], [sq * ca, cq * ca, -sa, -sa * d], [sq * sa, cq * sa, ca, ca * d], [0, 0, 0, 1.0]])
 
 
-def link_box_poses(q):
-    """q (7,) -> list of 9 (R (3,3), center (3,)) world poses of the link boxes (float64 modified-DH chain)."""
-    T = np.eye(4)
-    frames = []
-    for i in range(7):
-        a, d, al = franka.DH_A_D_ALPHA[i]
-        T = T @ _dh(a, d, al, q[i])
-        frames.append(T.copy())
-    sf = franka.static_frames().astype(np.float64)
-    out = []
-    for l in range(franka.N_LINKS):
-        F = frames[franka.LINK_FRAME[l]]
-        S = np.eye(4)
-        S[:3, :] = sf[l]
-        W = F @ S
-        out.append((W[:3, :3], W[:3, 3]))
-    return out
-
-
-def quat_xyzw_to_matrix(q):
-    x, y, z, w = np.asarray(q, dtype=np.float64) / np.linalg.norm(q)
-    return np.array(
-        [
-            [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
-            [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
-            [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)],
-        ]
-    )
-
-
-def obb_overlap(Ra, ca, ha, Rb, cb, hb, eps=1e-12) -> bool:
-    """separating-axis test for two oriented boxes (R columns = axes, c centre, h half extents)."""
-    R = Ra.T @ Rb
-    t = Ra.T @ (cb - ca)
-    A = np.abs(R) + eps
-    for i in range(3):
-        if abs(t[i]) > ha[i] + hb @ A[i]:
-            return False
-    for j in range(3):
-        if abs(t @ R[:, j]) > ha @ A[:, j] + hb[j]:
-            return False
-    for i in range(3):
-        for j in range(3):
-            ra = ha[(i + 1) % 3] * A[(i + 2) % 3, j] + ha[(i + 2) % 3] * A[(i + 1) % 3, j]
-            rb = hb[(j + 1) % 3] * A[i, (j + 2) % 3] + hb[(j + 2) % 3] * A[i, (j + 1) % 3]
-            if abs(t[(i + 2) % 3] * R[(i + 1) % 3, j] - t[(i + 1) % 3] * R[(i + 2) % 3, j]) > ra + rb:
-                return False
-    return True
-
-
-def configuration_in_collision(q, obstacle_config, link_mesh_extents=None) -> bool:
-    he = franka.link_half_extents(link_mesh_extents).astype(np.float64)
-    poses = link_box_poses(np.asarray(q, dtype=np.float64))
-    for o in np.asarray(obstacle_config, dtype=np.float64):
-        Ro, co, ho = quat_xyzw_to_matrix(o[3:7]), o[:3], o[7:10] / 2
-        for l, (Rl, cl) in enumerate(poses):
-            if obb_overlap(Rl, cl, he[l], Ro, co, ho):
-                return True
-    return False
-
-
-def geometric_success(trajectory, obstacle_config, substeps: int = 4, link_mesh_extents=None) -> dict:
-    """trajectory (7, N).  success = within joint limits and no link-box / obstacle-box intersection at any waypoint or
-    interpolated configuration.  Returns dict(success, first_collision_waypoint, within_limits)."""
+def geometric_success(trajectory, guide, substeps: int = 4) -> dict:
+    """ONE trajectory (7, N) against the scene of `guide` (an IntersectionVolumeGuide): dict(success,
+    first_collision_waypoint, within_limits).  Runs on the GPU (one-row batch of guide.success_rows)."""
     tr = np.asarray(trajectory, dtype=np.float64)
-    lo, hi = franka.joint_limits()
-    within = bool(np.all(tr >= lo[:, None] - 1e-9) and np.all(tr <= hi[:, None] + 1e-9))
-    n = tr.shape[1]
-    first = -1
-    for i in range(n):
-        stops = [0.0] if i == n - 1 else [s / substeps for s in range(substeps)]
-        for s in stops:
-            q = tr[:, i] if s == 0.0 else (1 - s) * tr[:, i] + s * tr[:, i + 1]
-            if configuration_in_collision(q, obstacle_config, link_mesh_extents):
-                first = i
-                break
-        if first >= 0:
-            break
-    return dict(success=bool(within and first < 0), first_collision_waypoint=first, within_limits=within)
+    if tr.ndim != 2 or tr.shape[0] != 7:
+        raise ValueError(f"trajectory must be (7, N), got {tr.shape}")
+    r = guide.success_rows(tr[None], substeps=substeps)
+    return dict(success=bool(r["ok"][0]), first_collision_waypoint=int(r["first"][0]), within_limits=bool(r["within"][0]))
+
+
+def success_rate(trajectories, guide, substeps: int = 4) -> dict:
+    """every row of a batch (B, 7, N): dict(rows_ok, rows, rate, ok (B,), first (B,), within (B,)) - the batch form of the
+    reference's running tally `t_success / i` (infer_serial.py:99)."""
+    r = guide.success_rows(trajectories, substeps=substeps)
+    r["rate"] = r["rows_ok"] / max(r["rows"], 1)
+    return r
 
 
 # the fixed flange / hand chain behind joint 7: rows 8-10 of the reference's modified-DH table [a, d, alpha, theta]

@@ -63,6 +63,16 @@ def dh_table() -> np.ndarray:
     return t
 
 
+def dh_table_f64() -> np.ndarray:
+    """(7, 4) float64 [a, d, cos(alpha), sin(alpha)]: the success check walks the chain in float64."""
+    t = np.zeros((N_JOINTS, 4), dtype=np.float64)
+    t[:, 0] = DH_A_D_ALPHA[:, 0]
+    t[:, 1] = DH_A_D_ALPHA[:, 1]
+    t[:, 2] = np.cos(DH_A_D_ALPHA[:, 2])
+    t[:, 3] = np.sin(DH_A_D_ALPHA[:, 2])
+    return t
+
+
 JOINT_LOWER_DEG = (-166.0, -101.0, -166.0, -176.0, -166.0, -1.0, -166.0)
 JOINT_UPPER_DEG = (166.0, 101.0, 166.0, -4.0, 166.0, 215.0, 166.0)
 

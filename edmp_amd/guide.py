@@ -40,7 +40,7 @@ class IntersectionVolumeGuide:
     pybullet_data at run time (lib/guide.py:245-282); defaults to the documented placeholder table.
     """
 
-    def __init__(self, obstacle_config, device, guide_cfgs, batch_size, *, link_mesh_extents=None):
+    def __init__(self, obstacle_config, device, guide_cfgs, batch_size, *, link_mesh_extents=None, obstacle_kinds=None):
         self.ctx = get_context(device)
         self.device = self.ctx.device
         self.guide_cfgs = guide_cfgs
@@ -61,6 +61,10 @@ class IntersectionVolumeGuide:
         self._sched = np.ascontiguousarray(np.asarray(guide_cfgs["guidance_schedule"], dtype=np.float64))
         self._rows_token = None
         self._slot = new_slot_key()
+        # 0 cuboid / 1 cylinder per obstacle row: only the success check reads it (the guide itself sees cylinders as
+        # (r, r, h) boxes, quirk Q9).  The reference's loader orders obstacle_config cuboids first, then cylinders
+        # (datasets/load_test_dataset.py:141-149), so kinds = [0] * num_cuboids + [1] * num_cylinders there.
+        self._kinds = None if obstacle_kinds is None else self._check_kinds(obstacle_kinds)
         self._bind()
 
     # ---- binding -----------------------------------------------------------------------------------------------
@@ -82,9 +86,23 @@ class IntersectionVolumeGuide:
                                    self._cls_clr.shape[0], self.T, _capi.as_pf(self._half), _capi.as_pf(self._dh), _capi.as_pf(self._sf)),
             "edmp_scene_set",
         )
-        ctx.bound_guide = self
         self._rows_token = None
         self._set_rows(self._sched)
+        if self._kinds is not None:
+            _capi.check(ctx.lib.edmp_scene_set_shapes(ctx.h, _capi.as_pi32(self._kinds), no), "edmp_scene_set_shapes")
+        ctx.bound_guide = self  # only a completely built object counts as bound
+
+    def _check_kinds(self, kinds):
+        k = np.ascontiguousarray(np.asarray(kinds, dtype=np.int32).reshape(-1))
+        if k.shape[0] != self.obstacle_config.shape[0] or not np.all((k == 0) | (k == 1)):
+            raise ValueError("obstacle_kinds: one entry per obstacle, 0 = cuboid, 1 = cylinder")
+        return k
+
+    def set_obstacle_kinds(self, kinds):
+        """mark obstacle rows as true cylinders (dims = (r, r, h)) for the success check (lib/environment.py:249-268)."""
+        self._kinds = self._check_kinds(kinds)
+        self._bind()
+        _capi.check(self.ctx.lib.edmp_scene_set_shapes(self.ctx.h, _capi.as_pi32(self._kinds), self._kinds.shape[0]), "edmp_scene_set_shapes")
 
     def _set_rows(self, sched):
         sched = np.ascontiguousarray(np.asarray(sched, dtype=np.float64))
@@ -181,6 +199,33 @@ class IntersectionVolumeGuide:
         idx = C.c_int()
         _capi.check(ctx.lib.edmp_row_swept_volumes_dev(ctx.h, ptr(X), B, N, _capi.as_pd(s), _capi.as_pd(g), ptr(vols), C.byref(idx)), "edmp_row_swept_volumes_dev")
         return ctx.to_host(vols), idx.value
+
+    def success_rows(self, trajectories, substeps: int = 4, return_device: bool = False):
+        """Geometric success of EVERY row (edmp_success_rows_dev; stands for RobotEnvironment.benchmark_trajectory,
+        lib/environment.py:632-680, and the tally of infer_serial.py:94-99,165-168): trajectories (B,7,N) ndarray or device
+        tensor -> dict(ok (B,) bool, first (B,) int32 first colliding waypoint or -1, within (B,) bool, rows_ok, rows_within,
+        rows_collision_free, rows).  With return_device the three per-row arrays stay int32 device tensors."""
+        self._bind()
+        ctx = self.ctx
+        if isinstance(trajectories, torch.Tensor) and trajectories.is_cuda:
+            X = ctx.adopt(trajectories.to(torch.float64).contiguous())
+        else:
+            X = ctx.to_dev(np.asarray(trajectories, dtype=np.float64), torch.float64)
+        if X.dim() != 3 or X.shape[1] != 7:
+            raise ValueError(f"trajectories must be (B, 7, N), got {tuple(X.shape)}")
+        B, N = X.shape[0], X.shape[2]
+        flags = ctx.empty((3, B), torch.int32)
+        counts = (C.c_int32 * 4)()
+        dh = np.ascontiguousarray(franka.dh_table_f64())
+        _capi.check(ctx.lib.edmp_success_rows_dev(ctx.h, ptr(X), B, N, int(substeps), _capi.as_pd(dh), C.c_void_p(flags[0].data_ptr()),
+                                                  C.c_void_p(flags[1].data_ptr()), C.c_void_p(flags[2].data_ptr()), counts), "edmp_success_rows_dev")
+        out = dict(rows_ok=int(counts[0]), rows_within=int(counts[1]), rows_collision_free=int(counts[2]), rows=int(counts[3]))
+        if return_device:
+            out.update(ok=flags[0], first=flags[1], within=flags[2])
+        else:
+            f = ctx.to_host(flags)
+            out.update(ok=f[0].astype(bool), first=f[1].copy(), within=f[2].astype(bool))
+        return out
 
     def choose_best_trajectory(self, start, goal, trajectories):
         _, idx = self.row_swept_volumes(start, goal, trajectories)

@@ -47,9 +47,11 @@ class SyntheticDataset:
     all_ik_goals).  scene_type 'tabletop' = yaw-only cuboids, anything else = free orientations.  IK goals are seeded
     in-limit configurations (robofin/ikfast are not available)."""
 
-    def __init__(self, dataset_type="synthetic", d_path=None, scene_types=("stress",), num_scenes_per_type=1, n_obstacles=8, n_ik=100):
+    def __init__(self, dataset_type="synthetic", d_path=None, scene_types=("stress",), num_scenes_per_type=1, n_obstacles=8, n_ik=100, n_cylinders=0):
         self.dataset_type = dataset_type
-        self.n_obstacles, self.n_ik = int(n_obstacles), int(n_ik)
+        self.n_obstacles, self.n_ik, self.n_cylinders = int(n_obstacles), int(n_ik), int(n_cylinders)
+        if not 0 <= self.n_cylinders <= self.n_obstacles:
+            raise ValueError("n_cylinders must lie in [0, n_obstacles]")
         n = 1 if num_scenes_per_type is None or num_scenes_per_type < 0 else int(num_scenes_per_type)
         self.data_nums = {st: n for st in scene_types}
 
@@ -59,7 +61,12 @@ class SyntheticDataset:
         start, _ = random_start_goal(seed)
         lo, hi = joint_limits()
         iks = np.random.RandomState(seed + 2).uniform(lo, hi, (self.n_ik, 7))
-        return oc, oc.copy(), np.zeros((0, 10)), oc.shape[0], 0, start, iks
+        # like the reference's loader: cuboids first, then cylinders entering obstacle_config as (r, r, h) boxes
+        # (datasets/load_test_dataset.py:136-149); cylinder_config rows are [xyz, quat xyzw, radius, height] (:131-134)
+        nb = self.n_obstacles - self.n_cylinders
+        oc[nb:, 8] = oc[nb:, 7]
+        cyl = np.concatenate([oc[nb:, :7], oc[nb:, 7:8], oc[nb:, 9:10]], axis=1) if self.n_cylinders else np.zeros((0, 9))
+        return oc, oc[:nb].copy(), cyl, nb, self.n_cylinders, start, iks
 
 
 # ---- neutral scene files -------------------------------------------------------------------------------------------

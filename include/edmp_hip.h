@@ -119,6 +119,24 @@ int edmp_row_swept_volumes_dev(edmp_ctx* ctx, const double* X_dev, int B, int N,
  * minimum; NaN counts as the smallest value (the first NaN wins).  The selection step of edmp_row_swept_volumes_dev. */
 int edmp_argmin_dev(edmp_ctx* ctx, const float* v_dev, int n, int* index_host);
 
+/* ---- plan success: the reference's simulator check, restated geometrically ------------------------------------ */
+/* The guide sees every obstacle as a box (cylinders enter as (r, r, h) boxes, datasets/load_test_dataset.py:136-139) but the
+ * reference's success check spawns TRUE cylinders (RobotEnvironment.spawn_collision_cylinders, lib/environment.py:249-268:
+ * radius = config[7], height = config[8], axis = local z).  kind[i] = 0 cuboid (default after edmp_scene_set) / 1 cylinder
+ * for obstacle row i of the obstacle_config given to edmp_scene_set.  Only edmp_success_rows_dev reads it. */
+int edmp_scene_set_shapes(edmp_ctx* ctx, const int32_t* kind, int n_obstacles);
+/* stands for RobotEnvironment.benchmark_trajectory + check_collisions (lib/environment.py:632-680, 591-608), the success
+ * tally of infer_serial.py:94-99,165-168, for EVERY row of a batch: X (B,7,N) f64 on the device; a row succeeds iff all its
+ * waypoints lie inside the joint limits (:659-661) and none of the 9 link boxes (lib/guide.py:243-342, f64 modified-DH
+ * poses) meets an obstacle - exact oriented-box test against cuboids, exact box / finite-cylinder test against cylinders -
+ * at any waypoint or at any of `substeps` joint-space interpolated configurations per segment ((1 - s/S) q_i + (s/S) q_i+1,
+ * s = 0..S-1; the last waypoint once).  pybullet itself is third-party and absent: a geometric stand-in, not the simulator.
+ * dh_f64 (host, optional): (7,4) f64 rows [a, d, cos(alpha), sin(alpha)]; NULL widens the f32 table of edmp_scene_set.
+ * Outputs (device, each optional): ok (B,) int32 0/1, first (B,) int32 = first colliding waypoint or -1, within (B,) int32
+ * 0/1.  counts_host (optional, synchronises): [rows ok, rows within limits, rows collision-free, B]. */
+int edmp_success_rows_dev(edmp_ctx* ctx, const double* X_dev, int B, int N, int substeps, const double* dh_f64, int32_t* ok_dev,
+                          int32_t* first_dev, int32_t* within_dev, int32_t* counts_host);
+
 /* ---- sampler: Diffusion ------------------------------------------------------------------------------ */
 /* replaces Diffusion.__init__/schedule_variance (diffusion/diffusion.py:10-20, 37-49) */
 int edmp_sampler_init(edmp_ctx* ctx, int T, double variance_thresh);

@@ -51,9 +51,13 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True):
         for scene_num in range(dataset.data_nums[scene_type]):
             if max_scenes is not None and i >= max_scenes:
                 break
-            obstacle_config, _, _, _, _, start_joints, all_ik_goals = dataset.fetch_data(scene_num=scene_num, scene_type=scene_type)
+            obstacle_config, _, _, num_cuboids, num_cylinders, start_joints, all_ik_goals = dataset.fetch_data(scene_num=scene_num, scene_type=scene_type)
             t0 = time.time()
-            guide = IntersectionVolumeGuide(obstacle_config=obstacle_config, device=device, guide_cfgs=guide_cfgs, batch_size=total_batch_size)
+            # obstacle_config = cuboids first, then cylinders as (r, r, h) boxes (datasets/load_test_dataset.py:141-149); the
+            # success check spawns the latter as true cylinders (infer_serial.py:159-163 -> lib/environment.py:249-268)
+            kinds = np.concatenate([np.zeros(int(num_cuboids), dtype=np.int32), np.ones(int(num_cylinders), dtype=np.int32)])
+            guide = IntersectionVolumeGuide(obstacle_config=obstacle_config, device=device, guide_cfgs=guide_cfgs, batch_size=total_batch_size,
+                                            obstacle_kinds=kinds)
             # IK-goal filter                                                              infer_serial.py:117-129
             volumes = guide.cost(torch.tensor(all_ik_goals.reshape((-1, 7, 1))), 0, batch_size=all_ik_goals.shape[0]).sum(axis=(1, 2)).cpu().numpy()
             indices = np.argsort(volumes)
@@ -65,18 +69,21 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True):
             vols, idx = guide.row_swept_volumes(start_joints, goal_joints, trajectories)
             trajectory = trajectories[idx]
             t_plan = time.time() - t0
-            # success: pybullet execution (lib/environment.py:632-680) is unavailable -> exact oriented-box check along the
-            # interpolated trajectory; the guide's own (conservative, AABB) criterion is reported next to it
-            chk = EV.geometric_success(trajectory, obstacle_config)
-            success = int(chk["success"])
+            # success: pybullet execution (lib/environment.py:632-680) is unavailable -> exact link-box vs cuboid / cylinder
+            # check along the interpolated trajectory, for EVERY row of the batch in one kernel (csrc/success.hip); the
+            # scene's success is the chosen row's flag (infer_serial.py:165-168), the batch rate is reported next to it,
+            # as is the guide's own (conservative, AABB) criterion
+            chk = guide.success_rows(trajectories)
+            success = int(chk["ok"][idx])
             t_success += success
             i += 1
             results.append(dict(scene_type=scene_type, scene_num=scene_num, best_row=int(idx), swept_volume=float(vols[idx]), success_proxy=success,
-                                aabb_volume_zero=bool(ED.geometric_success(float(vols[idx]), trajectory)), first_collision_waypoint=chk["first_collision_waypoint"],
+                                rows_ok=chk["rows_ok"], rows=chk["rows"],
+                                aabb_volume_zero=bool(ED.geometric_success(float(vols[idx]), trajectory)), first_collision_waypoint=int(chk["first"][idx]),
                                 path_length=EV.path_lengths(trajectory), sparc=EV.smoothness(trajectory), planning_time_s=t_plan, trajectory=trajectory))
             if verbose:
                 print(f"Scene {i} ({scene_type}/{scene_num}): planning {t_plan:.2f} s, best row {idx}, swept volume {vols[idx]:.4g}, "
-                      f"geometric success (proxy) {success}   running {t_success}/{i}")
+                      f"geometric success (proxy) {success} ({chk['rows_ok']}/{chk['rows']} rows of the batch)   running {t_success}/{i}")
     return results
 
 

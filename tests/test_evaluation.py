@@ -1,4 +1,5 @@
-"""CPU: host-side evaluation utilities (success proxy, metrics, scene files) — SURVEY.md §8f rows 1 and 3."""
+"""CPU: host-side evaluation utilities (metrics, scene files) — SURVEY.md §8f rows 1 and 3.  The success check runs on the
+GPU (tests/test_gpu_success.py); its CPU checker is tested in tests/test_success_oracle.py."""
 import json
 
 import numpy as np
@@ -6,58 +7,6 @@ import pytest
 
 from edmp_amd import evaluation as EV
 from edmp_amd import franka, scenes
-
-
-def test_host_fk_matches_oracle_fk():
-    import torch
-
-    from oracle import edmp_oracle as O
-
-    rs = np.random.RandomState(0)
-    lo, hi = franka.joint_limits()
-    q = rs.uniform(lo, hi)
-    lt = O.get_link_transform(torch.tensor(q[None, None, :], dtype=torch.float32))[0, 0].numpy()
-    for l, (R, c) in enumerate(EV.link_box_poses(q)):
-        assert np.allclose(R, lt[l, :3, :3], atol=2e-6) and np.allclose(c, lt[l, :3, 3], atol=2e-6)
-
-
-def test_obb_overlap_basics():
-    I = np.eye(3)
-    h = np.array([0.5, 0.5, 0.5])
-    assert EV.obb_overlap(I, np.zeros(3), h, I, np.array([0.9, 0, 0]), h)
-    assert not EV.obb_overlap(I, np.zeros(3), h, I, np.array([1.1, 0, 0]), h)
-    # rotated 45 deg about z: corner reaches sqrt(2)/2
-    Rz = EV.quat_xyzw_to_matrix([0, 0, np.sin(np.pi / 8), np.cos(np.pi / 8)])
-    assert EV.obb_overlap(I, np.zeros(3), h, Rz, np.array([1.15, 0, 0]), h)
-    assert not EV.obb_overlap(I, np.zeros(3), h, Rz, np.array([1.25, 0, 0]), h)
-    # an edge-edge separating axis case (AABB of the rotated box overlaps, the boxes do not)
-    Rx = EV.quat_xyzw_to_matrix([np.sin(np.pi / 8), 0, 0, np.cos(np.pi / 8)])
-    assert not EV.obb_overlap(Rz, np.zeros(3), h, Rx @ Rz, np.array([1.05, 1.05, 0.0]), h)
-
-
-def test_geometric_success_and_exactness_vs_aabb_guide():
-    lo, hi = franka.joint_limits()
-    start = scenes.DEFAULT_START
-    traj = np.tile(start[:, None], (1, 50))
-    far = np.array([[5.0, 0, 0, 0, 0, 0, 1, 0.2, 0.2, 0.2]])
-    assert EV.geometric_success(traj, far)["success"]
-    # put a box exactly on link 5's centre -> collision
-    R, c = EV.link_box_poses(start)[4]
-    hit = np.array([[*c, 0, 0, 0, 1, 0.1, 0.1, 0.1]])
-    r = EV.geometric_success(traj, hit)
-    assert not r["success"] and r["first_collision_waypoint"] == 0
-    out = traj.copy()
-    out[3, 7] = 0.3  # joint 4 upper limit is -4 deg
-    assert not EV.geometric_success(out, far)["success"] and not EV.geometric_success(out, far)["within_limits"]
-    # collision only between waypoints is caught by the interpolation
-    q0, q1 = start.copy(), start.copy()
-    q1[0] += 1.2
-    seg = np.concatenate([np.tile(q0[:, None], (1, 25)), np.tile(q1[:, None], (1, 25))], axis=1)
-    qm = 0.5 * (q0 + q1)
-    Rm, cm = EV.link_box_poses(qm)[6]
-    mid = np.array([[*cm, 0, 0, 0, 1, 0.02, 0.02, 0.02]])
-    assert not EV.configuration_in_collision(q0, mid) and not EV.configuration_in_collision(q1, mid)
-    assert not EV.geometric_success(seg, mid, substeps=8)["success"]
 
 
 def test_metrics():
@@ -107,3 +56,11 @@ def test_metrics_against_the_reference(golden):
         assert abs(sj - g["joint_sparc"][i]) <= 1e-9 and abs(sj - g["third_party_joint_sparc"][i]) <= 1e-9, (i, sj, g["joint_sparc"][i])
         assert abs(se - g["ee_sparc"][i]) <= 5e-4 * max(1.0, abs(g["ee_sparc"][i])), (i, se, g["ee_sparc"][i])  # f32 positions feed an FFT threshold
     assert EV.smoothness_metric(g["trajectories"][4], dt) == (0.0, 0.0)  # constant trajectory: the reference returns 0
+
+
+def test_synthetic_dataset_with_cylinders_follows_the_loader_contract():
+    ds = scenes.SyntheticDataset(scene_types=("stress",), n_obstacles=6, n_cylinders=2)
+    oc, cub, cyl, nb, ncyl, start, iks = ds.fetch_data(0, "stress")
+    assert (nb, ncyl) == (4, 2) and cub.shape == (4, 10) and cyl.shape == (2, 9) and oc.shape == (6, 10)
+    assert np.array_equal(oc[:4], cub) and np.array_equal(oc[4:, 7], oc[4:, 8])  # cylinders enter as (r, r, h) boxes, after the cuboids
+    assert np.array_equal(cyl[:, 7], oc[4:, 7]) and np.array_equal(cyl[:, 8], oc[4:, 9])

@@ -1,0 +1,189 @@
+"""GPU: the batch success check (edmp_success_rows_dev, csrc/success.hip) against its CPU checker
+(oracle/success_oracle.py) — SURVEY.md §8f row 3.  Stands for RobotEnvironment.benchmark_trajectory
+(lib/environment.py:632-680) and the per-scene tally of infer_serial.py:94-99,165-168."""
+import numpy as np
+import pytest
+
+from tests.util import T, cfgs_for
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _guide(scene, B, kinds=None):
+    from edmp_amd.guide import IntersectionVolumeGuide
+
+    return IntersectionVolumeGuide(scene, DEV, cfgs_for([1], B), B, obstacle_kinds=kinds)
+
+
+def _rows(rs, B, N, lo, hi, spread=1.0):
+    """smooth random trajectories: a straight joint-space line between two in-limit configurations plus a low-frequency
+    wobble, so that rows sweep through the scene instead of jumping."""
+    a, b = rs.uniform(lo, hi, (B, 7)), rs.uniform(lo, hi, (B, 7))
+    b = a + spread * (b - a)
+    t = np.linspace(0, 1, N)
+    X = a[:, :, None] * (1 - t) + b[:, :, None] * t
+    X += 0.15 * rs.standard_normal((B, 7, 1)) * np.sin(np.pi * t)[None, None, :]
+    return X
+
+
+def _compare(res, ref, what):
+    bad = np.nonzero((res["ok"] != ref["ok"]) | (res["first"] != ref["first"]) | (res["within"] != ref["within"]))[0]
+    assert bad.size == 0, (what, bad[:10], res["first"][bad[:10]], ref["first"][bad[:10]])
+
+
+def test_success_rows_vs_checker_on_random_rows():
+    from edmp_amd import franka, scenes
+    from oracle import success_oracle as SO
+
+    rs = np.random.RandomState(42)
+    lo, hi = franka.joint_limits()
+    B, N = 640, 50
+    scene = scenes.random_scene(5, 10)
+    scene[:, 7:10] *= 0.5  # smaller obstacles: a useful mix of colliding and free rows
+    kinds = np.array([0, 0, 1, 0, 1, 0, 0, 1, 0, 0], dtype=np.int32)
+    scene[kinds == 1, 8] = scene[kinds == 1, 7]  # cylinders enter as (r, r, h)
+    X = _rows(rs, B, N, lo, hi, spread=0.35)
+    # rows outside the limits: just outside (beyond the 1e-9 slack), far outside, exactly on the limit (inside)
+    X[5, 3, 10] = hi[3] + 2e-9
+    X[6, 0, 49] = lo[0] - 0.3
+    X[7, 1, 0] = hi[1]
+    X[8, 5, 20] = lo[5] - 0.5e-9  # inside the slack
+    g = _guide(scene, B, kinds)
+    res = g.success_rows(X, substeps=4)
+    ref = SO.success_rows(X, scene, substeps=4, kinds=kinds)
+    _compare(res, ref, "random rows")
+    assert not res["within"][5] and not res["within"][6] and res["within"][7] and res["within"][8]
+    assert res["rows"] == B and res["rows_ok"] == int(ref["ok"].sum()) and res["rows_within"] == int(ref["within"].sum())
+    assert res["rows_collision_free"] == int((ref["first"] < 0).sum())
+    n_ok = int(ref["ok"].sum())
+    assert 0.1 * B < n_ok < 0.9 * B, n_ok  # the case mix is meaningful
+    # the cylinders matter: as (r, r, h) boxes (what the guide sees) some rows flip
+    as_boxes = SO.success_rows(X, scene, substeps=4, kinds=None)
+    assert (as_boxes["first"] != ref["first"]).any()
+    res_b = _guide(scene, B).success_rows(X, substeps=4)
+    _compare(res_b, as_boxes, "cylinders as boxes")
+    # other sub-step counts and a device-tensor input
+    import torch
+
+    for S in (1, 7):
+        r2 = g.success_rows(torch.from_numpy(X[:64]).to(DEV), substeps=S)
+        _compare(r2, SO.success_rows(X[:64], scene, substeps=S, kinds=kinds), f"substeps {S}")
+
+
+def _touching_cases(kind, n_cases, seed):
+    """(q, scene(gap), kinds) generators: ONE small obstacle face to face with link box l of configuration q, along the
+    link's axis `ax`, such that no OTHER link box comes near it - the pair under test alone decides the row's flag."""
+    from scipy.spatial.transform import Rotation
+
+    from edmp_amd import franka
+    from oracle import success_oracle as SO
+
+    rs = np.random.RandomState(seed)
+    lo, hi = franka.joint_limits()
+    he = franka.link_half_extents().astype(np.float64)
+    out = []
+    while len(out) < n_cases:
+        q = rs.uniform(lo, hi)
+        poses = SO.link_box_poses(q)
+        # links 0..6 only: the static frames of hand / finger carry a float32 rotation (c = 0.70710677, s = 0.70710680,
+        # lib/guide.py:318-340) that is orthonormal to 2e-8 only, so "face to face at 1e-9" cannot be constructed on them
+        l, ax, sgn = rs.randint(0, 7), rs.randint(0, 3), (1.0 if rs.rand() < 0.5 else -1.0)
+        Rl, cl = poses[l]
+        if kind == 0:
+            ho = rs.uniform(0.005, 0.02, 3)
+            reach, Ro, dims = ho[ax], Rl, 2 * ho
+        else:
+            # cylinder: cap contact (axis along the link axis `ax`) or side contact (axis perpendicular to it)
+            r, h = rs.uniform(0.005, 0.02), rs.uniform(0.01, 0.04)
+            cap = rs.rand() < 0.5
+            zc = Rl[:, ax] if cap else Rl[:, (ax + 1) % 3]
+            xc = Rl[:, (ax + 1) % 3] if cap else Rl[:, (ax + 2) % 3]
+            Ro = np.stack([xc, np.cross(zc, xc), zc], axis=1)
+            reach, dims = (h / 2 if cap else r), np.array([r, r, h])
+        quat = Rotation.from_matrix(Ro).as_quat()
+        # slide the obstacle off the face centre so that contact is not always centre to centre
+        off = sum(rs.uniform(-0.5, 0.5) * he[l, m] * Rl[:, m] for m in range(3) if m != ax)
+
+        def scene(gap, cl=cl, Rl=Rl, l=l, ax=ax, sgn=sgn, reach=reach, quat=quat, dims=dims, off=off):
+            co = cl + off + sgn * Rl[:, ax] * (he[l, ax] + reach + gap)
+            return np.concatenate([co, quat, dims])[None]
+
+        # every other link must stay clear of a 5 mm inflated copy of the obstacle at the touching position
+        big = scene(0.0).copy()
+        big[0, 7:10] += 0.01
+        Rb, cb, hb, _ = SO.obstacle_shapes(big)
+        if any(SO.obb_overlap(poses[m][0], poses[m][1], he[m], Rb[0], cb[0], np.full(3, hb[0].max() * 1.5)) for m in range(9) if m != l):
+            continue
+        out.append((q, scene))
+    return out
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_touching_and_just_separated_pairs(kind):
+    """a constant trajectory at q*, ONE obstacle placed face to face with a link box at gap g: the flag must flip between
+    g = -1e-9 and g = +1e-9 (far below float32 resolution at arm's length) and agree with the checker."""
+    from oracle import success_oracle as SO
+
+    kinds = np.array([kind], dtype=np.int32)
+    for case, (q, scene) in enumerate(_touching_cases(kind, 16, 7 + kind)):
+        X = np.tile(q[None, :, None], (2, 1, 6))
+        flags = {}
+        for gap in (-1e-3, -1e-9, 1e-9, 1e-3):
+            sc = scene(gap)
+            ref = SO.success_rows(X, sc, substeps=2, kinds=kinds)
+            res = _guide(sc, 2, kinds).success_rows(X, substeps=2)
+            _compare(res, ref, (case, gap))
+            flags[gap] = bool(res["ok"][0])
+        assert flags == {-1e-3: False, -1e-9: False, 1e-9: True, 1e-3: True}, (case, flags)
+
+
+def test_success_inside_the_sampler_flow_and_gather():
+    """the flags of a finished denoise_guided batch: best row's flag + batch counts, as bench.py / infer_serial.py use them."""
+    from edmp_amd import dist as ED
+    from edmp_amd import scenes
+    from edmp_amd import weights as W
+    from edmp_amd.diffusion import Diffusion
+    from edmp_amd.temporalunet import TemporalUNet
+    from oracle import success_oracle as SO
+    from tests.util import TINY_DIMS
+
+    cfgs = cfgs_for([1, 10, 11], 4)
+    B = cfgs["total_batch_size"]
+    from edmp_amd.guide import IntersectionVolumeGuide
+
+    scene = scenes.random_scene(7, 8)
+    guide = IntersectionVolumeGuide(scene, DEV, cfgs, B)
+    net = TemporalUNet(None, 7, 32, DEV, dims=TINY_DIMS, state_dict=W.init_state_dict(5, 7, 32, TINY_DIMS), max_batch=B)
+    dif = Diffusion(T, DEV)
+    noise = np.random.RandomState(3).standard_normal((T + 1, B, 7, 50))
+    Xd = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=scenes.DEFAULT_START, goal=scenes.DEFAULT_GOAL, noise=noise,
+                            return_device=True)
+    res = guide.success_rows(Xd)
+    ref = SO.success_rows(Xd.cpu().numpy(), scene)
+    _compare(res, ref, "sampler output")
+    vols, idx = guide.row_swept_volumes(scenes.DEFAULT_START, scenes.DEFAULT_GOAL, Xd)
+    best = ED.gather_best(float(vols[idx]), idx, Xd[idx].cpu().numpy(), bool(res["ok"][idx]), rows_ok=res["rows_ok"], rows=res["rows"])
+    assert best["rows_ok"] == int(ref["ok"].sum()) and best["rows"] == B and best["success"] == bool(ref["ok"][idx])
+
+
+def test_success_error_behaviour():
+    import ctypes as C
+
+    from edmp_amd import _capi, scenes
+    from edmp_amd.runtime import get_context
+
+    g = _guide(scenes.random_scene(1, 3), 2)
+    with pytest.raises(ValueError):
+        g.success_rows(np.zeros((2, 6, 50)))
+    with pytest.raises(ValueError):
+        g.set_obstacle_kinds([0, 1])
+    with pytest.raises(ValueError):
+        g.set_obstacle_kinds([0, 2, 0])
+    ctx = get_context(DEV)
+    g._bind()
+    assert ctx.lib.edmp_success_rows_dev(ctx.h, None, 2, 50, 4, None, None, None, None, None) == _capi.load().edmp_version() * 0 - 1
+    assert b"edmp_success_rows_dev" in ctx.lib.edmp_last_error()
+    bad = (C.c_int32 * 3)(0, 5, 0)
+    assert ctx.lib.edmp_scene_set_shapes(ctx.h, bad, 3) == -1
