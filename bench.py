@@ -188,6 +188,10 @@ def main():
                                       "within the joint limits and no link box meeting an obstacle (exact oriented-box / cylinder test, 4 interpolated configurations per "
                                       "segment) - a geometric stand-in for the reference's pybullet check (lib/environment.py:632-680), which is unavailable offline; "
                                       "random-init denoiser (no trained weights offline): the rate says nothing about planning quality, it is reported, never gated"},
+            # one logical batch: host time of the per-guided-step hook (Python ctypes callback that enqueues the RCCL
+            # all-reduce of sum(g^2) on the context's stream), rank 0, last call
+            "allreduce_hook": (None if not logical else {"calls_per_denoise": dif.hook_stats["calls"], "avg_us": 1e6 * dif.hook_stats["total_s"] / max(dif.hook_stats["calls"], 1),
+                                                        "max_us": 1e6 * dif.hook_stats["max_s"]}),
             "unet_flops_per_traj_step": {"nominal": nominal, "direct_form_after_tap_skipping": net.flops_direct_form(), "issued_mfma": executed, "survey": SURVEY_FLOPS_PER_TRAJ_STEP,
                                          "note": "issued < direct form: the L=2 / L=4 Conv1dBlocks run in Karatsuba form (3 of 4 resp. 9 of 14 matrix products)"},
         }

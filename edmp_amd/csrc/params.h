@@ -41,30 +41,11 @@ struct RcbP {
     float* dst;            // [B][L][Cout]
     int Cout;
     int B;
-    // folded residual 1x1 conv of the block input (rcb_conv_kernel<.,.,true>): its weights [Cout][Cin] sit right behind
+    // folded residual 1x1 conv of the block input (wide_conv_kernel<.., RES = true>): its weights [Cout][Cin] sit right behind
     // the five conv taps in W (tap index 5); res_out [B][L][Cout] receives conv + res_bias for conv2's epilogue
     float* res_out;
     const float* res_bias;
     int gx_shift = -1, ng_shift = -1;  // wide_conv_kernel: log2 of the XCDs across the channel groups (wide.hip: xcd_split) and of the group count, set by the launcher; -1 = plain mapping
-};
-
-struct BlkP {
-    const float* src1;
-    const float* src2;
-    int C1, C2;
-    const float* W1;  // [5][C][Cin]
-    const float* b1;
-    const float* g1;
-    const float* be1;
-    const float* tb;  // [C] time bias of step t
-    const float* W2;  // [5][C][C]
-    const float* b2;
-    const float* g2;
-    const float* be2;
-    const float* Wr;  // [C][Cin] residual 1x1 conv (RES) or nullptr (identity: src1 is the residual)
-    const float* br;
-    float* dst;  // [B][L][C]
-    int B;
 };
 
 // whole-level kernel (level.hip)

@@ -465,6 +465,7 @@ extern "C" int edmp_unet_slot(edmp_ctx* ctx, uint64_t key) {
     if (!ctx) return EDMP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return EDMP_ERR_HIP;
     ctx->epoch++;
+    (void)prof_fold(ctx);  // pending per-op event brackets belong to the model that recorded them
     return select_slot(ctx->unet_slots, ctx->unet, ctx->unet_key, key, ctx->unet_cap, unet_destroy, unet_complete);
 }
 

@@ -15,6 +15,8 @@
 //     Taps that fall into the zero padding are never issued.
 //   * the whole time-embedding MLP chain depends on t only and is precomputed for t = 1..T at load (time_table_kernel).
 //   * the layer program (which kernel, which buffers) is built once in edmp_unet_load / edmp_unet_load_packed.
+#include <memory>
+
 #include "common.h"
 #define EDMP_STAMPS_DEFINE 1  // unity builds with -DEDMP_STAMPS: the stamp buffer lives here
 #include "params.h"
@@ -114,20 +116,20 @@ static RawNet inventory(const edmp_unet_desc& d) {
 // ---------------------------------------------------------------------------------------------------------------
 // device program
 // ---------------------------------------------------------------------------------------------------------------
-enum OpKind { OP_CONV = 0, OP_GN = 1, OP_RCB = 2, OP_BLK = 3, OP_WRS = 4, OP_LVL = 5 };  // OP_LVL: a whole 32/64-channel level (level.hip)  // OP_WRS: down/up-sampling conv of a wide level on wide_conv_kernel
+// OP_RCB: Conv1dBlock of a wide level on wide_conv_kernel; OP_WRS: down/up-sampling conv of a wide level on wide_conv_kernel;
+// OP_LVL: a whole 32/64-channel level (level.hip); OP_CONV / OP_GN: the generic fallback (any architecture)
+enum OpKind { OP_CONV = 0, OP_GN = 1, OP_RCB = 2, OP_WRS = 4, OP_LVL = 5 };
 struct Op {
     OpKind kind;
     ConvP cv;
     GnP gn;
     RcbP rc;
-    BlkP bk;      // OP_BLK: a whole residual block
     LevelP lv;    // OP_LVL: a whole level
     int lv_variant;
     int lv_tb1, lv_tb2;  // offsets of the two blocks' time biases in the time-bias row
-    int bk_variant;
     int rc_L;     // OP_RCB / OP_WRS: input positions
+    int rc_form;  // OP_RCB: 0 direct | 2 / 4 Karatsuba form at L = 2 / 4 (decided when the model was built)
     int wrs_kind; // OP_WRS: WK_DOWN / WK_UP
-    int rc_rows;  // OP_RCB: 0 = rcb_conv_kernel (wide levels), else rcb_rows_kernel variant
     int tb_off;   // GN: offset into the time-bias row, -1 if none
     int branch;   // 0 = main stream; 1 = fork point (record before this op); 2 = runs on the side stream; 3 = join (wait) before this op
     double flops_nominal, flops_exec;  // per trajectory: every tap | MFMA work actually issued (padding taps skipped, Karatsuba forms)
@@ -154,6 +156,8 @@ struct UNet {
     struct Tap { int which; const float* p; int C, L; };
     std::vector<Tap> taps;
     double flops_nominal = 0, flops_exec = 0, flops_direct = 0;
+    int layout = 0;  // layout id of the packed weight image (Packer::layout_id)
+    bool fuse_tail = true;  // EDMP_NO_FUSED_TAIL at build time
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -390,671 +394,6 @@ EDMP_LEVEL_INSTANCES(EDMP_X)
 #endif
 namespace edmp {
 
-// ---------------------------------------------------------------------------------------------------------------
-// Fused Conv1dBlock of the NARROW levels (Cout <= 128, L in {7, 13, 25, 50}): same fusion as rcb_conv_kernel, other
-// shape.  Here the GEMM rows are (sample, position) pairs and the columns are channels: a workgroup owns SB whole
-// samples x CB channels (whole GroupNorm groups), stages the samples' input [SB][L+4 (zero halo)][KC] once per K step
-// and reads the 5 tap-shifted A operands of Conv1d(k=5, pad=2) straight out of that tile (row + tap) — no im2col, no
-// per-tap reload — against the [5][CB][KC] weight slab.  Statistics are complete in the workgroup; the raw conv output
-// never reaches HBM.  grid = (Cout/CB, B/SB).
-// Per (sample, group) GroupNorm statistics of a raw conv tile Y[row = sample*L + position][YS] held in LDS: unit u =
-// (sample b, group g of 2^cgs channels), 16 lanes per unit, 16 units per pass over the workgroup.  Each lane reads its
-// share ONCE as float4 (4 consecutive channels of one position; 2^cgs >= 4) and keeps it in registers for the second,
-// centred pass (two-pass variance like torch's group_norm).  Writes stat[2*(b*16+g)] = mean, [...+1] = 1/sqrt(var+eps).
-template <int L>
-__device__ __forceinline__ void group_stats_lds(const float* __restrict__ Y, int YS, float* __restrict__ stat, int units, int G, int cgs,
-                                                int tid) {
-    constexpr int NE4 = (L + 3) / 4;  // float4 per lane at the widest group (16 channels): ceil(L*16/4/16)
-    const int l16 = tid & 15;
-    const int cgm = (1 << cgs) - 1;
-    const int n4 = (L << cgs) >> 2;
-    const float inv_n = 1.0f / (float)(L << cgs);
-    for (int u = tid >> 4; u < units; u += 16) {
-        const int b = u / G, g = u - b * G;
-        const float* yb = Y + (b * L) * YS + (g << cgs);
-        float4 v[NE4];
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < NE4; ++i) {
-            const int e = 4 * (l16 + 16 * i);
-            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (l16 + 16 * i < n4) {
-                v[i] = *reinterpret_cast<const float4*>(yb + (e >> cgs) * YS + (e & cgm));
-                sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-            }
-        }
-        sum += __shfl_xor(sum, 1, 64);
-        sum += __shfl_xor(sum, 2, 64);
-        sum += __shfl_xor(sum, 4, 64);
-        sum += __shfl_xor(sum, 8, 64);
-        const float mean = sum * inv_n;
-        float sq = 0.f;
-#pragma unroll
-        for (int i = 0; i < NE4; ++i) {
-            if (l16 + 16 * i < n4) {
-                const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
-                sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-            }
-        }
-        sq += __shfl_xor(sq, 1, 64);
-        sq += __shfl_xor(sq, 2, 64);
-        sq += __shfl_xor(sq, 4, 64);
-        sq += __shfl_xor(sq, 8, 64);
-        if (l16 == 0) {
-            stat[2 * (b * 16 + g)] = mean;
-            stat[2 * (b * 16 + g) + 1] = 1.0f / sqrtf(sq * inv_n + 1e-5f);
-        }
-    }
-}
-
-template <int CB, int L, int SB, int KC>
-struct RowsCfg {
-    static constexpr int LDK = KC + 4;
-    static constexpr int ROWS = SB * L;
-    static constexpr int MT = (ROWS + 31) / 32;
-    static constexpr int NT = CB / 32;
-    static constexpr int NTILE = MT * NT;
-    static constexpr int TPW = (NTILE + 3) / 4;
-    static constexpr int XR = SB * (L + 4);
-    static constexpr int A_FL = XR * LDK;
-    static constexpr int B_FL = 5 * CB * LDK;
-    static constexpr int STAGE = A_FL + B_FL;
-    static constexpr int A_F4 = ROWS * (KC / 4);
-    static constexpr int B_F4 = 5 * CB * (KC / 4);
-    static constexpr int NA = (A_F4 + 255) / 256;
-    static constexpr int NB = (B_F4 + 255) / 256;
-    static constexpr int YS = CB + 4;
-    static constexpr int Y_FL = MT * 32 * YS;
-    static constexpr int STAT_FL = 2 * SB * 16;
-    static constexpr size_t lds_bytes() {
-        size_t a = 2 * (size_t)STAGE * sizeof(float);
-        size_t b = ((size_t)Y_FL + STAT_FL) * sizeof(float);
-        return a > b ? a : b;
-    }
-};
-
-template <int CB, int L, int SB, int KC>
-__global__ __launch_bounds__(256) void rcb_rows_kernel(RcbP p) {
-    using Cf = RowsCfg<CB, L, SB, KC>;
-    constexpr int LDK = Cf::LDK, ROWS = Cf::ROWS, NT = Cf::NT, NTILE = Cf::NTILE, TPW = Cf::TPW;
-    constexpr int A_FL = Cf::A_FL, STAGE = Cf::STAGE, A_F4 = Cf::A_F4, B_F4 = Cf::B_F4, NA = Cf::NA, NB = Cf::NB;
-    constexpr int YS = Cf::YS, Y_FL = Cf::Y_FL, F4R = KC / 4;
-    static_assert(NA <= 4 && NB <= 10 && TPW <= 2, "staging macros cover NA <= 4, NB <= 10, two tiles per wave");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-
-    constexpr int SK = (L == 13) ? 0 : 1;  // (L = 25, 50 variants share slot 1 with L = 7: the last launch wins)
-    EDMP_STAMP(SK, 0)
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int co0 = blockIdx.x * CB;
-    const int b0 = blockIdx.y * SB;
-    const int Cin = p.C1 + p.C2;
-    const int ch1 = p.C1 / KC, ch2 = p.C2 / KC;
-    const int nK = ch1 + ch2;
-
-    // zero both A stages once: the 2+2 halo rows of every sample stay zero (= Conv1d's zero padding)
-    for (int i = tid; i < A_FL / 4; i += 256) {
-        *reinterpret_cast<float4*>(lds + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(lds + STAGE + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-
-#define EDMP_REP4(M) M(0) M(1) M(2) M(3)
-#define EDMP_REP10(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9)
-#define EDMP_DECL_XA(i)                                                                         \
-    const int fa##i = tid + i * 256;                                                            \
-    const bool pa##i = (i < NA) && (fa##i < A_F4);                                              \
-    const int ra_r##i = min(fa##i / F4R, ROWS - 1);                                             \
-    const int ga1_##i = (min(b0 + ra_r##i / L, p.B - 1) * L + ra_r##i % L) * p.C1 + (fa##i % F4R) * 4; \
-    const int ga2_##i = (min(b0 + ra_r##i / L, p.B - 1) * L + ra_r##i % L) * p.C2 + (fa##i % F4R) * 4; \
-    const int la##i = ((ra_r##i / L) * (L + 4) + ra_r##i % L + 2) * LDK + (fa##i % F4R) * 4;    \
-    float4 xa##i = make_float4(0.f, 0.f, 0.f, 0.f);
-#define EDMP_DECL_XB(i)                                                                         \
-    const int fb##i = tid + i * 256;                                                            \
-    const bool pb##i = (i < NB) && (fb##i < B_F4);                                              \
-    const int fbc##i = min(fb##i, B_F4 - 1);                                                    \
-    const int gb##i = ((fbc##i / (CB * F4R)) * p.Cout + co0 + (fbc##i % (CB * F4R)) / F4R) * Cin + (fbc##i % F4R) * 4; \
-    const int lb##i = A_FL + ((fbc##i / (CB * F4R)) * CB + (fbc##i % (CB * F4R)) / F4R) * LDK + (fbc##i % F4R) * 4;   \
-    float4 xb##i = make_float4(0.f, 0.f, 0.f, 0.f);
-    EDMP_REP4(EDMP_DECL_XA)
-    EDMP_REP10(EDMP_DECL_XB)
-#define EDMP_LD_XA(i) \
-    if (pa##i) xa##i = *reinterpret_cast<const float4*>(src_ + (first_ ? ga1_##i : ga2_##i) + ci0_);
-#define EDMP_LD_XB(i) \
-    if (pb##i) xb##i = *reinterpret_cast<const float4*>(p.W + gb##i + wofs_);
-#define EDMP_ST_XA(i) \
-    if (pa##i) *reinterpret_cast<float4*>(sn_ + la##i) = xa##i;
-#define EDMP_ST_XB(i) \
-    if (pb##i) *reinterpret_cast<float4*>(sn_ + lb##i) = xb##i;
-#define EDMP_ROWS_FETCH(nc)                                          \
-    {                                                                \
-        const bool first_ = (nc) < ch1;                              \
-        const float* src_ = first_ ? p.src1 : p.src2;                \
-        const int ci0_ = (first_ ? (nc) : (nc)-ch1) * KC;            \
-        const int wofs_ = (first_ ? 0 : p.C1) + ci0_;                \
-        EDMP_REP4(EDMP_LD_XA) EDMP_REP10(EDMP_LD_XB)                 \
-    }
-#define EDMP_ROWS_COMMIT(stage_ptr)                    \
-    {                                                  \
-        float* sn_ = (stage_ptr);                      \
-        EDMP_REP4(EDMP_ST_XA) EDMP_REP10(EDMP_ST_XB)   \
-    }
-
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        acc0[i] = 0.0f;
-        acc1[i] = 0.0f;
-    }
-    // this wave's tiles: j = wave + 4*t -> (row tile mt, channel tile nt)
-    const int j0 = wave, j1 = wave + 4;
-    const bool has0 = j0 < NTILE, has1 = (TPW > 1) && (j1 < NTILE);
-    // conv bias of this wave's tiles, requested up front (see rcb_conv_kernel)
-    const float bias_t0 = p.bias[co0 + (min(j0, NTILE - 1) % NT) * 32 + (lane & 31)];
-    const float bias_t1 = p.bias[co0 + (min(j1, NTILE - 1) % NT) * 32 + (lane & 31)];
-    const int fr = 4 * (lane >> 5);
-    const int r0 = min((j0 / NT) * 32 + (lane & 31), ROWS - 1);
-    const int r1 = min((j1 / NT) * 32 + (lane & 31), ROWS - 1);
-    const int arow0 = ((r0 / L) * (L + 4) + r0 % L) * LDK + fr;  // + tap*LDK
-    const int arow1 = ((r1 / L) * (L + 4) + r1 % L) * LDK + fr;
-    const int brow0 = A_FL + ((j0 % NT) * 32 + (lane & 31)) * LDK + fr;  // + tap*CB*LDK
-    const int brow1 = A_FL + ((j1 % NT) * 32 + (lane & 31)) * LDK + fr;
-
-    __syncthreads();  // halo zeros are in place before the first commit lands
-    EDMP_ROWS_FETCH(0)
-    EDMP_ROWS_COMMIT(lds)
-    __syncthreads();
-    EDMP_STAMP(SK, 1)
-
-#define EDMP_ROWS_TILE(st, accv, arow, brow)                                                          \
-    _Pragma("unroll") for (int k = 0; k < 5; ++k) {                                                    \
-        const float* a_s = (st) + (arow) + k * LDK;                                                    \
-        const float* b_s = (st) + (brow) + k * (CB * LDK);                                             \
-        _Pragma("unroll") for (int q = 0; q < KC / 8; ++q) {                                           \
-            const float4 a4 = *reinterpret_cast<const float4*>(a_s + 8 * q);                           \
-            const float4 b4 = *reinterpret_cast<const float4*>(b_s + 8 * q);                           \
-            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, accv, 0, 0, 0);                    \
-            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, accv, 0, 0, 0);                    \
-            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, accv, 0, 0, 0);                    \
-            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, accv, 0, 0, 0);                    \
-        }                                                                                              \
-    }
-#define EDMP_ROWS_COMPUTE(st)                                    \
-    if (has0) { EDMP_ROWS_TILE(st, acc0, arow0, brow0) }         \
-    if (has1) { EDMP_ROWS_TILE(st, acc1, arow1, brow1) }
-
-    for (int kk = 0; kk < nK - 1; ++kk) {
-        const int cur = kk & 1;
-        EDMP_ROWS_FETCH(kk + 1)
-        __builtin_amdgcn_sched_barrier(0);
-        const float* st = lds + cur * STAGE;
-        EDMP_ROWS_COMPUTE(st)
-        __builtin_amdgcn_sched_barrier(0);
-        EDMP_ROWS_COMMIT(lds + (cur ^ 1) * STAGE)
-        __syncthreads();
-    }
-    {
-        const float* st = lds + ((nK - 1) & 1) * STAGE;
-        EDMP_ROWS_COMPUTE(st)
-    }
-    __syncthreads();
-#undef EDMP_ROWS_COMPUTE
-#undef EDMP_ROWS_TILE
-#undef EDMP_ROWS_FETCH
-#undef EDMP_ROWS_COMMIT
-#undef EDMP_LD_XA
-#undef EDMP_LD_XB
-#undef EDMP_ST_XA
-#undef EDMP_ST_XB
-#undef EDMP_DECL_XA
-#undef EDMP_DECL_XB
-#undef EDMP_REP4
-#undef EDMP_REP10
-    EDMP_STAMP(SK, 2)
-
-    // ---- epilogue: raw (+bias) -> LDS Y[row][channel]; per (sample, group) statistics; normalise, Mish, add, store
-    float* Y = lds;
-    float* stat = lds + Y_FL;  // [SB][16][2]
-    const int cg = p.Cout >> 3;       // channels per group (power of two)
-    const int cgs = __ffs(cg) - 1;    // log2(cg)
-    const int G = CB >> cgs;          // groups in this workgroup
-    // the final pass' affine parameters and addends are requested from global memory now: they land while the
-    // accumulators are spilled to LDS and the statistics are reduced
-    constexpr int NIT = (ROWS * (CB / 4) + 255) / 256;
-    static_assert(NIT <= 8, "epilogue prefetch covers 8 float4 per thread");
-    float4 g4[NIT], be4[NIT], ad4[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int f = min(tid + it * 256, ROWS * (CB / 4) - 1);
-        const int r = f / (CB / 4), c4 = f % (CB / 4);
-        const int ch = co0 + c4 * 4;
-        const int bb = min(b0 + r / L, p.B - 1);
-        g4[it] = *reinterpret_cast<const float4*>(p.gamma + ch);
-        be4[it] = *reinterpret_cast<const float4*>(p.beta + ch);
-        ad4[it] = make_float4(0.f, 0.f, 0.f, 0.f);  // one addend per launch (see rcb_conv_kernel)
-        if (p.add_res) ad4[it] = *reinterpret_cast<const float4*>(p.add_res + ((size_t)bb * L + r % L) * p.Cout + ch);
-        else if (p.add_tb) ad4[it] = *reinterpret_cast<const float4*>(p.add_tb + ch);
-    }
-    {
-        const int cc = lane & 31;
-        if (has0) {
-            const int mt = j0 / NT, nt = j0 % NT;
-            const float bias = bias_t0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                Y[row * YS + nt * 32 + cc] = acc0[r] + bias;
-            }
-        }
-        if (has1) {
-            const int mt = j1 / NT, nt = j1 % NT;
-            const float bias = bias_t1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                Y[row * YS + nt * 32 + cc] = acc1[r] + bias;
-            }
-        }
-    }
-    __syncthreads();
-    EDMP_STAMP(SK, 3)
-    group_stats_lds<L>(Y, YS, stat, SB * G, G, cgs, tid);
-    __syncthreads();
-    EDMP_STAMP(SK, 4)
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int f = tid + it * 256;
-        if (f < ROWS * (CB / 4)) {
-            const int r = f / (CB / 4), c4 = f % (CB / 4);
-            const int b = r / L, l = r % L;
-            if (b0 + b < p.B) {
-                const int cc = c4 * 4;
-                const int g = cc >> cgs;
-                const float mean = stat[2 * (b * 16 + g)], rstd = stat[2 * (b * 16 + g) + 1];
-                const float4 v = *reinterpret_cast<const float4*>(Y + r * YS + cc);
-                float4 o;
-                const float s0 = rstd * g4[it].x, s1 = rstd * g4[it].y, s2 = rstd * g4[it].z, s3 = rstd * g4[it].w;
-                o.x = mish_fast(v.x * s0 + (be4[it].x - s0 * mean)) + ad4[it].x;
-                o.y = mish_fast(v.y * s1 + (be4[it].y - s1 * mean)) + ad4[it].y;
-                o.z = mish_fast(v.z * s2 + (be4[it].z - s2 * mean)) + ad4[it].z;
-                o.w = mish_fast(v.w * s3 + (be4[it].w - s3 * mean)) + ad4[it].w;
-                *reinterpret_cast<float4*>(p.dst + ((size_t)(b0 + b) * L + l) * p.Cout + co0 + cc) = o;
-            }
-        }
-    }
-    EDMP_STAMP(SK, 5)
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// A WHOLE ResidualConvolutionBlock (blocks.py:137-166) in one launch, for the narrowest levels (C = 32 or 64 output
-// channels): a workgroup owns SB whole samples x ALL C channels, so after conv1 + GroupNorm + Mish + time-bias the
-// hidden activation h of its samples is complete in LDS and conv2 reads its tap-shifted operands straight from that
-// tile; the residual (identity, or the 1x1 conv of the block input accumulated next to conv1) is added in registers.
-// These levels are launch-latency-bound (a fused conv of 32 channels is ~10 us of which ~2 are MFMAs): halving the
-// number of launches is worth more than any in-kernel tuning.  grid = (1, B/SB).
-
-template <int C, int L, int SB, int KC1, bool RES>
-struct BlkCfg {
-    static constexpr int LDK1 = KC1 + 4, LDK2 = 36, HS = C + 4, YS = C + 4;
-    static constexpr int ROWS = SB * L, MT = (ROWS + 31) / 32, NT = C / 32, NTILE = MT * NT, TPW = (NTILE + 3) / 4;
-    static constexpr int XR = SB * (L + 4);
-    static constexpr int NSLAB = RES ? 6 : 5;
-    static constexpr int A1_FL = XR * LDK1, B1_FL = NSLAB * C * LDK1, STAGE1 = A1_FL + B1_FL;
-    static constexpr int B2_FL = 5 * C * LDK2;  // one K chunk of conv2's weights
-    static constexpr int H_FL = XR * HS;
-    static constexpr int Y_FL = MT * 32 * YS;
-    static constexpr int STAT_FL = 2 * SB * 16;
-    // conv1 needs a second stage only if it has more than one K chunk (an identity-residual block has Cin = C);
-    // conv2 has C/32 chunks.  Keeping LDS small lets two or three of these latency-bound workgroups share a CU.
-    static constexpr int NST1 = (!RES && C == KC1) ? 1 : 2;
-    static constexpr int NST2 = C / 32;
-    static constexpr int W1_ = NST1 * STAGE1, W2_ = Y_FL + STAT_FL, W3_ = NST2 * B2_FL;
-    static constexpr int WORK_FL = (W1_ > W2_ ? W1_ : W2_) > W3_ ? (W1_ > W2_ ? W1_ : W2_) : W3_;
-    static constexpr size_t lds_bytes() { return ((size_t)H_FL + WORK_FL) * sizeof(float); }
-    static constexpr int A1_F4 = ROWS * (KC1 / 4), B1_F4 = NSLAB * C * (KC1 / 4), B2_F4 = 5 * C * 8;
-    static constexpr int NA1 = (A1_F4 + 255) / 256, NB1 = (B1_F4 + 255) / 256, NB2 = (B2_F4 + 255) / 256;
-};
-
-template <int C, int L, int SB, int KC1, bool RES>
-__global__ __launch_bounds__(256) void rcb_block_kernel(BlkP p) {
-    using Cf = BlkCfg<C, L, SB, KC1, RES>;
-    constexpr int LDK1 = Cf::LDK1, LDK2 = Cf::LDK2, HS = Cf::HS, YS = Cf::YS, ROWS = Cf::ROWS, NT = Cf::NT, NTILE = Cf::NTILE, TPW = Cf::TPW;
-    constexpr int A1_FL = Cf::A1_FL, STAGE1 = Cf::STAGE1, B2_FL = Cf::B2_FL, H_FL = Cf::H_FL, Y_FL = Cf::Y_FL;
-    constexpr int A1_F4 = Cf::A1_F4, B1_F4 = Cf::B1_F4, B2_F4 = Cf::B2_F4, NA1 = Cf::NA1, NB1 = Cf::NB1, NB2 = Cf::NB2, F4R1 = KC1 / 4;
-    static_assert(NA1 <= 4 && NB1 <= 12 && NB2 <= 12 && TPW <= 2, "staging macros: NA1 <= 4, NB <= 12, two tiles per wave");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* H = lds;            // [SB][L+4][HS]: hidden activation with zero halos, lives across both phases
-    float* work = lds + H_FL;  // phase 1 stages | Y | phase 2 weight stages
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int b0 = blockIdx.y * SB;
-    const int Cin = p.C1 + p.C2;
-    const int ch1 = p.C1 / KC1, ch2 = p.C2 / KC1;
-    const int nK1 = ch1 + ch2;
-    // stamps: one variant only
-#define EDMP_BSTAMP(i) if constexpr (C == 64 && L == 25 && !RES) { EDMP_STAMP(7, i) }
-    EDMP_BSTAMP(0)
-
-    for (int i = tid; i < H_FL / 4; i += 256) *reinterpret_cast<float4*>(H + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < A1_FL / 4; i += 256) {
-        *reinterpret_cast<float4*>(work + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (Cf::NST1 == 2) *reinterpret_cast<float4*>(work + STAGE1 + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-
-#define EDMP_REP4(M) M(0) M(1) M(2) M(3)
-#define EDMP_REP12(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
-#define EDMP_DECL_XA(i)                                                                                         \
-    const int fa##i = tid + i * 256;                                                                            \
-    const bool pa##i = (i < NA1) && (fa##i < A1_F4);                                                            \
-    const int rr##i = min(fa##i / F4R1, ROWS - 1);                                                              \
-    const int ga1_##i = (min(b0 + rr##i / L, p.B - 1) * L + rr##i % L) * p.C1 + (fa##i % F4R1) * 4;             \
-    const int ga2_##i = (min(b0 + rr##i / L, p.B - 1) * L + rr##i % L) * p.C2 + (fa##i % F4R1) * 4;             \
-    const int la##i = ((rr##i / L) * (L + 4) + rr##i % L + 2) * LDK1 + (fa##i % F4R1) * 4;                      \
-    float4 xa##i = make_float4(0.f, 0.f, 0.f, 0.f);
-// weight slabs 0..4 = conv1 taps ([tap][C][Cin]), slab 5 = the residual 1x1 conv ([C][Cin])
-#define EDMP_DECL_XB(i)                                                                                         \
-    const int fb##i = min(tid + i * 256, B1_F4 - 1);                                                            \
-    const bool pb##i = (i < NB1) && (tid + i * 256 < B1_F4);                                                    \
-    const int sl##i = fb##i / (C * F4R1), co##i = (fb##i % (C * F4R1)) / F4R1, cq##i = (fb##i % F4R1) * 4;      \
-    const float* gb##i = (sl##i < 5 ? p.W1 + ((size_t)sl##i * C + co##i) * Cin : p.Wr + (size_t)co##i * Cin) + cq##i; \
-    const int lb##i = A1_FL + (sl##i * C + co##i) * LDK1 + cq##i;                                               \
-    float4 xb##i = make_float4(0.f, 0.f, 0.f, 0.f);
-    EDMP_REP4(EDMP_DECL_XA)
-    EDMP_REP12(EDMP_DECL_XB)
-#define EDMP_LD_XA(i) \
-    if (pa##i) xa##i = *reinterpret_cast<const float4*>(src_ + (first_ ? ga1_##i : ga2_##i) + ci0_);
-#define EDMP_LD_XB(i) \
-    if (pb##i) xb##i = *reinterpret_cast<const float4*>(gb##i + wofs_);
-#define EDMP_ST_XA(i) \
-    if (pa##i) *reinterpret_cast<float4*>(sn_ + la##i) = xa##i;
-#define EDMP_ST_XB(i) \
-    if (pb##i) *reinterpret_cast<float4*>(sn_ + lb##i) = xb##i;
-#define EDMP_BLK_FETCH1(nc)                                          \
-    {                                                                \
-        const bool first_ = (nc) < ch1;                              \
-        const float* src_ = first_ ? p.src1 : p.src2;                \
-        const int ci0_ = (first_ ? (nc) : (nc)-ch1) * KC1;           \
-        const int wofs_ = (first_ ? 0 : p.C1) + ci0_;                \
-        EDMP_REP4(EDMP_LD_XA) EDMP_REP12(EDMP_LD_XB)                 \
-    }
-#define EDMP_BLK_COMMIT1(stage_ptr)                    \
-    {                                                  \
-        float* sn_ = (stage_ptr);                      \
-        EDMP_REP4(EDMP_ST_XA) EDMP_REP12(EDMP_ST_XB)   \
-    }
-
-    f32x16 acc0, acc1, rac0, rac1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        acc0[i] = 0.0f;
-        acc1[i] = 0.0f;
-        rac0[i] = 0.0f;
-        rac1[i] = 0.0f;
-    }
-    const int j0 = wave, j1 = wave + 4;
-    const bool has0 = j0 < NTILE, has1 = (TPW > 1) && (j1 < NTILE);
-    // both convs' biases of this wave's tiles, requested up front (see rcb_conv_kernel)
-    const float b1_t0 = p.b1[(min(j0, NTILE - 1) % NT) * 32 + (lane & 31)], b1_t1 = p.b1[(min(j1, NTILE - 1) % NT) * 32 + (lane & 31)];
-    const float b2_t0 = p.b2[(min(j0, NTILE - 1) % NT) * 32 + (lane & 31)], b2_t1 = p.b2[(min(j1, NTILE - 1) % NT) * 32 + (lane & 31)];
-    float br_t0 = 0.f, br_t1 = 0.f;
-    if constexpr (RES) {
-        br_t0 = p.br[(min(j0, NTILE - 1) % NT) * 32 + (lane & 31)];
-        br_t1 = p.br[(min(j1, NTILE - 1) % NT) * 32 + (lane & 31)];
-    }
-    // both epilogues' final passes walk the tile as float4 with stride 256 threads, and 256 % (C/4) == 0: a thread always
-    // handles the same four channels `ecc`, so its affine parameters and time bias are loaded once, here, long before use
-    static_assert(256 % (C / 4) == 0, "a thread keeps its channel quad across the epilogue passes");
-    const int ecc = (tid % (C / 4)) * 4;
-    const float4 g1v = *reinterpret_cast<const float4*>(p.g1 + ecc), be1v = *reinterpret_cast<const float4*>(p.be1 + ecc);
-    const float4 tbv = *reinterpret_cast<const float4*>(p.tb + ecc);
-    const float4 g2v = *reinterpret_cast<const float4*>(p.g2 + ecc), be2v = *reinterpret_cast<const float4*>(p.be2 + ecc);
-    const int fr = 4 * (lane >> 5);
-    const int r0 = min((j0 / NT) * 32 + (lane & 31), ROWS - 1);
-    const int r1 = min((j1 / NT) * 32 + (lane & 31), ROWS - 1);
-    const int xr0 = (r0 / L) * (L + 4) + r0 % L, xr1 = (r1 / L) * (L + 4) + r1 % L;  // + tap
-    const int bcol0 = (j0 % NT) * 32 + (lane & 31), bcol1 = (j1 % NT) * 32 + (lane & 31);
-
-    __syncthreads();
-    EDMP_BLK_FETCH1(0)
-    EDMP_BLK_COMMIT1(work)
-    __syncthreads();
-    EDMP_BSTAMP(1)
-
-// conv1 taps (+ the residual slab at the centre tap) of one K chunk for one 32x32 tile
-#define EDMP_BLK_TILE1(st, accv, racv, xr, bcol)                                                      \
-    _Pragma("unroll") for (int k = 0; k < Cf::NSLAB; ++k) {                                            \
-        const float* a_s = (st) + ((xr) + (k < 5 ? k : 2)) * LDK1 + fr;                                \
-        const float* b_s = (st) + A1_FL + (k * C + (bcol)) * LDK1 + fr;                                \
-        _Pragma("unroll") for (int q = 0; q < KC1 / 8; ++q) {                                          \
-            const float4 a4 = *reinterpret_cast<const float4*>(a_s + 8 * q);                           \
-            const float4 b4 = *reinterpret_cast<const float4*>(b_s + 8 * q);                           \
-            if (k < 5) {                                                                               \
-                accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, accv, 0, 0, 0);                \
-                accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, accv, 0, 0, 0);                \
-                accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, accv, 0, 0, 0);                \
-                accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, accv, 0, 0, 0);                \
-            } else {                                                                                   \
-                racv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, racv, 0, 0, 0);                \
-                racv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, racv, 0, 0, 0);                \
-                racv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, racv, 0, 0, 0);                \
-                racv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, racv, 0, 0, 0);                \
-            }                                                                                          \
-        }                                                                                              \
-    }
-#define EDMP_BLK_COMPUTE1(st)                                          \
-    if (has0) { EDMP_BLK_TILE1(st, acc0, rac0, xr0, bcol0) }           \
-    if (has1) { EDMP_BLK_TILE1(st, acc1, rac1, xr1, bcol1) }
-
-    for (int kk = 0; kk < nK1 - 1; ++kk) {
-        const int cur = kk & 1;
-        EDMP_BLK_FETCH1(kk + 1)
-        __builtin_amdgcn_sched_barrier(0);
-        EDMP_BLK_COMPUTE1(work + cur * STAGE1)
-        __builtin_amdgcn_sched_barrier(0);
-        EDMP_BLK_COMMIT1(work + (cur ^ 1) * STAGE1)
-        __syncthreads();
-    }
-    EDMP_BLK_COMPUTE1(work + ((nK1 - 1) & 1) * STAGE1)
-    EDMP_BSTAMP(2)
-#undef EDMP_BLK_COMPUTE1
-#undef EDMP_BLK_TILE1
-#undef EDMP_BLK_FETCH1
-#undef EDMP_BLK_COMMIT1
-#undef EDMP_LD_XA
-#undef EDMP_LD_XB
-#undef EDMP_ST_XA
-#undef EDMP_ST_XB
-#undef EDMP_DECL_XA
-#undef EDMP_DECL_XB
-
-    // conv2's first weight chunk is requested now; it lands under epilogue 1
-#define EDMP_DECL_W2(i)                                                                                  \
-    const int f2##i = min(tid + i * 256, B2_F4 - 1);                                                     \
-    const bool p2##i = (i < NB2) && (tid + i * 256 < B2_F4);                                             \
-    const float* g2p##i = p.W2 + ((size_t)(f2##i / (C * 8)) * C + (f2##i % (C * 8)) / 8) * C + (f2##i % 8) * 4; \
-    const int l2##i = ((f2##i / (C * 8)) * C + (f2##i % (C * 8)) / 8) * LDK2 + (f2##i % 8) * 4;           \
-    float4 w2##i = make_float4(0.f, 0.f, 0.f, 0.f);
-    EDMP_REP12(EDMP_DECL_W2)
-#define EDMP_LD_W2(i) \
-    if (p2##i) w2##i = *reinterpret_cast<const float4*>(g2p##i + ci2_);
-#define EDMP_ST_W2(i) \
-    if (p2##i) *reinterpret_cast<float4*>(sn_ + l2##i) = w2##i;
-#define EDMP_BLK_FETCH2(nc)       \
-    {                             \
-        const int ci2_ = (nc)*32; \
-        EDMP_REP12(EDMP_LD_W2)    \
-    }
-#define EDMP_BLK_COMMIT2(stage_ptr)  \
-    {                                \
-        float* sn_ = (stage_ptr);    \
-        EDMP_REP12(EDMP_ST_W2)       \
-    }
-    EDMP_BLK_FETCH2(0)
-    __syncthreads();  // every wave is done with the conv1 stages
-
-    // ---- epilogue 1: Y = conv1 + b1 -> statistics -> h = Mish(GN(Y)) + tb, written into the haloed H tile
-    float* Y = work;
-    float* stat = work + Y_FL;
-    constexpr int CG = C / 8;                      // channels per group
-    constexpr int CGS = (CG == 4) ? 2 : 3;         // log2
-    constexpr int G = 8;
-    {
-        const int cc = lane & 31;
-        if (has0) {
-            const int mt = j0 / NT, nt = j0 % NT;
-            const float bias = b1_t0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Y[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * YS + nt * 32 + cc] = acc0[r] + bias;
-        }
-        if (has1) {
-            const int mt = j1 / NT, nt = j1 % NT;
-            const float bias = b1_t1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Y[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * YS + nt * 32 + cc] = acc1[r] + bias;
-        }
-    }
-    __syncthreads();
-// per (sample, group) mean / rstd of the Y tile, 16 lanes per unit, two-pass
-#define EDMP_BLK_STATS() group_stats_lds<L>(Y, YS, stat, SB * G, G, CGS, tid);
-    EDMP_BLK_STATS()
-    __syncthreads();
-#pragma unroll
-    for (int it1 = 0; it1 < (ROWS * (C / 4) + 255) / 256; ++it1) {
-        const int f = tid + it1 * 256;
-        if (f >= ROWS * (C / 4)) break;
-        const int r = f / (C / 4), cc = (f % (C / 4)) * 4;
-        const int b = r / L, l = r % L;
-        const int g = cc >> CGS;
-        const float mean = stat[2 * (b * 16 + g)], rstd = stat[2 * (b * 16 + g) + 1];
-        const float4 v = *reinterpret_cast<const float4*>(Y + r * YS + cc);
-        const float4 g4 = g1v, be4 = be1v, tb4 = tbv;  // cc == ecc
-        float4 o;
-        const float s0 = rstd * g4.x, s1 = rstd * g4.y, s2 = rstd * g4.z, s3 = rstd * g4.w;
-        o.x = mish_fast(v.x * s0 + (be4.x - s0 * mean)) + tb4.x;
-        o.y = mish_fast(v.y * s1 + (be4.y - s1 * mean)) + tb4.y;
-        o.z = mish_fast(v.z * s2 + (be4.z - s2 * mean)) + tb4.z;
-        o.w = mish_fast(v.w * s3 + (be4.w - s3 * mean)) + tb4.w;
-        *reinterpret_cast<float4*>(H + (b * (L + 4) + l + 2) * HS + cc) = o;
-    }
-    __syncthreads();  // H complete, Y dead
-    EDMP_BSTAMP(3)
-
-    // ---- phase 2: conv2 over the C channels of H (A operand straight from the H tile), weights streamed per 32-channel chunk
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        acc0[i] = 0.0f;
-        acc1[i] = 0.0f;
-    }
-    EDMP_BLK_COMMIT2(work)
-    __syncthreads();
-    constexpr int nK2 = C / 32;
-#define EDMP_BLK_TILE2(st, accv, xr, bcol, ci0)                                                        \
-    _Pragma("unroll") for (int k = 0; k < 5; ++k) {                                                    \
-        const float* a_s = H + ((xr) + k) * HS + (ci0) + fr;                                           \
-        const float* b_s = (st) + (k * C + (bcol)) * LDK2 + fr;                                        \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                \
-            const float4 a4 = *reinterpret_cast<const float4*>(a_s + 8 * q);                           \
-            const float4 b4 = *reinterpret_cast<const float4*>(b_s + 8 * q);                           \
-            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, accv, 0, 0, 0);                    \
-            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, accv, 0, 0, 0);                    \
-            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, accv, 0, 0, 0);                    \
-            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, accv, 0, 0, 0);                    \
-        }                                                                                              \
-    }
-#pragma unroll
-    for (int kk = 0; kk < nK2; ++kk) {
-        if (kk + 1 < nK2) EDMP_BLK_FETCH2(kk + 1)
-        __builtin_amdgcn_sched_barrier(0);
-        const float* st2 = work + (kk & 1) * B2_FL;
-        if (has0) { EDMP_BLK_TILE2(st2, acc0, xr0, bcol0, kk * 32) }
-        if (has1) { EDMP_BLK_TILE2(st2, acc1, xr1, bcol1, kk * 32) }
-        __builtin_amdgcn_sched_barrier(0);
-        if (kk + 1 < nK2) EDMP_BLK_COMMIT2(work + ((kk + 1) & 1) * B2_FL)
-        __syncthreads();
-    }
-#undef EDMP_BLK_TILE2
-#undef EDMP_BLK_FETCH2
-#undef EDMP_BLK_COMMIT2
-#undef EDMP_LD_W2
-#undef EDMP_ST_W2
-#undef EDMP_DECL_W2
-#undef EDMP_REP4
-#undef EDMP_REP12
-
-    EDMP_BSTAMP(4)
-    // ---- epilogue 2: conv2 + b2 (and the residual conv + br) -> LDS, statistics, then one coalesced float4 pass:
-    //      out = Mish(GN(conv2)) + residual.  The identity residual (the block input) is requested from global memory first,
-    //      so it lands under the spill + statistics; the residual-conv tile reuses the dead H tile.
-    constexpr int NIT = (ROWS * (C / 4) + 255) / 256;
-    float4 res4[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        res4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (!RES) {
-            const int r = min(tid + it * 256, ROWS * (C / 4) - 1) / (C / 4);
-            const int bb = min(b0 + r / L, p.B - 1);
-            res4[it] = *reinterpret_cast<const float4*>(p.src1 + ((size_t)bb * L + r % L) * C + ecc);
-        }
-    }
-    float* R = H;  // [ROWS][YS] residual-conv tile (RES); every wave left the conv2 loop through its closing barrier
-    static_assert(ROWS * YS <= H_FL, "the residual tile fits in the H tile");
-    {
-        const int cc = lane & 31;
-        if (has0) {
-            const int mt = j0 / NT, nt = j0 % NT;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                Y[row * YS + nt * 32 + cc] = acc0[r] + b2_t0;
-                if constexpr (RES)
-                    if (row < ROWS) R[row * YS + nt * 32 + cc] = rac0[r] + br_t0;
-            }
-        }
-        if (has1) {
-            const int mt = j1 / NT, nt = j1 % NT;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                Y[row * YS + nt * 32 + cc] = acc1[r] + b2_t1;
-                if constexpr (RES)
-                    if (row < ROWS) R[row * YS + nt * 32 + cc] = rac1[r] + br_t1;
-            }
-        }
-    }
-    __syncthreads();
-    EDMP_BSTAMP(5)
-    EDMP_BLK_STATS()
-#undef EDMP_BLK_STATS
-    __syncthreads();
-    EDMP_BSTAMP(6)
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int f = tid + it * 256;
-        if (f < ROWS * (C / 4)) {
-            const int r = f / (C / 4);
-            const int b = r / L, l = r % L;
-            if (b0 + b < p.B) {
-                const int g = ecc >> CGS;
-                const float mean = stat[2 * (b * 16 + g)], rstd = stat[2 * (b * 16 + g) + 1];
-                const float4 v = *reinterpret_cast<const float4*>(Y + r * YS + ecc);
-                float4 rs = res4[it];
-                if constexpr (RES) rs = *reinterpret_cast<const float4*>(R + r * YS + ecc);
-                const float s0 = rstd * g2v.x, s1 = rstd * g2v.y, s2 = rstd * g2v.z, s3 = rstd * g2v.w;
-                float4 o;
-                o.x = mish_fast(v.x * s0 + (be2v.x - s0 * mean)) + rs.x;
-                o.y = mish_fast(v.y * s1 + (be2v.y - s1 * mean)) + rs.y;
-                o.z = mish_fast(v.z * s2 + (be2v.z - s2 * mean)) + rs.z;
-                o.w = mish_fast(v.w * s3 + (be2v.w - s3 * mean)) + rs.w;
-                *reinterpret_cast<float4*>(p.dst + ((size_t)(b0 + b) * L + l) * C + ecc) = o;
-            }
-        }
-    }
-    EDMP_BSTAMP(7)
-#undef EDMP_BSTAMP
-}
-
 // GroupNorm(8 groups, eps 1e-5, biased variance) -> Mish -> (+ time bias[c] | + residual[b,l,c]) in place.
 // One wave per (sample, group); the (C/8) x L elements of the group stay in registers between the passes.
 template <int EPL>  // elements per lane
@@ -1209,118 +548,42 @@ static int launch_gn(const GnP& p, hipStream_t s) {
 // position-tile kernel (wide.hip) instances: channels per GroupNorm group cg = Cout/8 and the input length select
 // the tile height MS (32 samples for cg >= 32, 16 for the 128-channel levels)
 static int wide_ms(int cout) { return cout / 8 >= 32 ? 32 : 16; }
-// the L = 2 convolutions of the 512-channel levels in Karatsuba form (3 instead of 4 matrix products; wide.hip WK_K5K2);
-// EDMP_NO_KARATSUBA=1 selects the direct form (A/B runs)
-static bool karatsuba_l2() {
-    static const bool on = getenv("EDMP_NO_KARATSUBA") == nullptr;
-    return on;
-}
-// ... and the L = 4 convolutions of the 256/512-channel levels in the nested form (9 instead of 14 products; WK_K5K4)
-static bool fuse_tail() {  // EDMP_NO_FUSED_TAIL=1: the step's tail stays its own launch (ablation / A-B)
-    static const bool on = !getenv("EDMP_NO_FUSED_TAIL");
-    return on;
-}
-static bool karatsuba_l4() {
-    static const bool on = getenv("EDMP_NO_KARATSUBA") == nullptr && getenv("EDMP_NO_KARATSUBA4") == nullptr;
-    return on;
-}
+// Builder switches, read from the environment WHEN A MODEL IS BUILT (edmp_unet_load*) and frozen into its layer program:
+// two models built under different settings can live side by side in one process (A/B runs, the adversarial-weights test).
+// EDMP_NO_KARATSUBA=1: the L = 2 convolutions of the 512-channel levels in the direct form instead of the Karatsuba form
+// (3 instead of 4 matrix products; wide.hip WK_K5K2) - and, with it or with EDMP_NO_KARATSUBA4=1, the L = 4 convolutions of
+// the 256/512-channel levels (nested form, 9 instead of 14 products; WK_K5K4).  EDMP_NO_FUSED_TAIL=1: the step's tail stays
+// its own launch.
+static bool karatsuba_l2() { return getenv("EDMP_NO_KARATSUBA") == nullptr; }
+static bool karatsuba_l4() { return getenv("EDMP_NO_KARATSUBA") == nullptr && getenv("EDMP_NO_KARATSUBA4") == nullptr; }
+static bool fuse_tail() { return !getenv("EDMP_NO_FUSED_TAIL"); }
 static bool rcb_supported(int cout, int L, int c1, int c2) {
     const int cg = cout / 8;
     const bool shape = (cg == 64 && (L == 2 || L == 4)) || (cg == 32 && (L == 4 || L == 7)) || (cg == 16 && (L == 7 || L == 13));
     return shape && cout % 8 == 0 && c1 % 32 == 0 && c2 % 32 == 0 && (c2 == 0 || c2 == c1);  // wide.hip: equal halves of a concat
 }
-template <int CB, int L, int SB, int KC>
-static int launch_rows_t(const RcbP& p, hipStream_t s) {
-    static bool attr_set = false;
-    constexpr size_t bytes = RowsCfg<CB, L, SB, KC>::lds_bytes();
-    if (!attr_set) {
-        EDMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcb_rows_kernel<CB, L, SB, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        attr_set = true;
-    }
-    dim3 grid(p.Cout / CB, (p.B + SB - 1) / SB);
-    hipLaunchKernelGGL((rcb_rows_kernel<CB, L, SB, KC>), grid, dim3(256), bytes, s, p);
-    return EDMP_OK;
-}
-// narrow levels: (Cout, L) -> instance; input channels must be whole 32-chunks (or the padded 8-channel network input)
-static int rows_variant(int cout, int L, int c1, int c2) {
-    const bool k32 = c1 % 32 == 0 && c2 % 32 == 0 && c1 > 0;
-    const bool k8 = c1 == 8 && c2 == 0;
-    if (cout == 32 && L == 50) return k8 ? 1 : (k32 ? 2 : 0);
-    if (!k32) return 0;
-    if (cout == 32 && L == 25) return 3;
-    if (cout == 64 && L == 25) return 4;
-    if ((cout == 64 || cout == 128) && L == 13) return 5;
-    if (cout == 128 && L == 7) return 6;
+// form: 0 direct | 2 Karatsuba at L = 2 | 4 nested Karatsuba at L = 4 (rcb_form, frozen into the op at build time)
+static int rcb_form(int cout, int L) {
+    const int cg = cout / 8;
+    if (cg == 64 && L == 2 && karatsuba_l2()) return 2;
+    if (cg >= 32 && L == 4 && karatsuba_l4()) return 4;
     return 0;
 }
-static int launch_rows(const RcbP& p, int variant, hipStream_t s) {
-    switch (variant) {
-        case 1: return launch_rows_t<32, 50, 2, 8>(p, s);
-        case 2: return launch_rows_t<32, 50, 2, 32>(p, s);
-        case 3: return launch_rows_t<32, 25, 5, 32>(p, s);
-        case 4: return launch_rows_t<64, 25, 5, 32>(p, s);
-        case 5: return launch_rows_t<64, 13, 8, 32>(p, s);  // 8 samples: 256 workgroups = ONE round on 256 CUs (4 samples ran two rounds, each with its own prologue + epilogue)
-        case 6: return launch_rows_t<64, 7, 9, 32>(p, s);
-    }
-    set_error("no narrow fused kernel variant %d", variant);
-    return EDMP_ERR_STATE;
-}
-template <int C, int L, int SB, int KC1, bool RES>
-static int launch_blk_t(const BlkP& p, hipStream_t s) {
-    static bool attr_set = false;
-    constexpr size_t bytes = BlkCfg<C, L, SB, KC1, RES>::lds_bytes();
-    static_assert(bytes <= 160 * 1024, "whole-block kernel exceeds the 160 KiB LDS of a CU");
-    if (!attr_set) {
-        EDMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rcb_block_kernel<C, L, SB, KC1, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        attr_set = true;
-    }
-    dim3 grid(1, (p.B + SB - 1) / SB);
-    hipLaunchKernelGGL((rcb_block_kernel<C, L, SB, KC1, RES>), grid, dim3(256), bytes, s, p);
-    return EDMP_OK;
-}
-// whole-residual-block kernel variants: (Cout, L, stored input channels) -> id (0 = none); odd ids carry the 1x1 residual conv
-static int blk_variant(int cout, int L, int c1, int c2, bool has_res) {
-    auto div = [&](int kc) { return c1 % kc == 0 && c2 % kc == 0 && c1 > 0; };
-    if (!has_res && (c2 != 0 || c1 != cout)) return 0;
-    int base = 0;
-    if (cout == 32 && L == 50) base = (c1 == 8 && c2 == 0) ? 1 : (div(32) ? 3 : 0);
-    else if (cout == 64 && L == 25 && div(16)) base = 5;
-    else if (cout == 64 && L == 13 && div(32)) base = 7;
-    else if (cout == 32 && L == 25 && div(32)) base = 9;
-    if (!base) return 0;
-    if (base == 1) return has_res ? 1 : 0;
-    return has_res ? base : base + 1;
-}
-static int launch_blk(const BlkP& p, int variant, hipStream_t s) {
-    switch (variant) {
-        case 1: return launch_blk_t<32, 50, 2, 8, true>(p, s);
-        case 3: return launch_blk_t<32, 50, 2, 32, true>(p, s);
-        case 4: return launch_blk_t<32, 50, 2, 32, false>(p, s);
-        case 5: return launch_blk_t<64, 25, 4, 16, true>(p, s);
-        case 6: return launch_blk_t<64, 25, 4, 16, false>(p, s);
-        case 7: return launch_blk_t<64, 13, 4, 32, true>(p, s);
-        case 8: return launch_blk_t<64, 13, 4, 32, false>(p, s);
-        case 9: return launch_blk_t<32, 25, 4, 32, true>(p, s);
-        case 10: return launch_blk_t<32, 25, 4, 32, false>(p, s);
-    }
-    set_error("no whole-block kernel variant %d", variant);
-    return EDMP_ERR_STATE;
-}
-static int launch_rcb(const RcbP& p, int L, hipStream_t s) {
+static int launch_rcb(const RcbP& p, int L, int form, hipStream_t s) {
     const int cg = p.Cout / 8;
     const bool res = p.res_out != nullptr;
 #define EDMP_K5(MS, CG, GS, LL) \
     return res ? launch_wide_t<WK_K5, MS, CG, GS, LL, true>(p, s) : launch_wide_t<WK_K5, MS, CG, GS, LL, false>(p, s);
     if (cg == 64 && L == 2) {
-        if (karatsuba_l2()) return res ? launch_wide_t<WK_K5K2, 32, 64, 64, 2, true>(p, s) : launch_wide_t<WK_K5K2, 32, 64, 64, 2, false>(p, s);
+        if (form == 2) return res ? launch_wide_t<WK_K5K2, 32, 64, 64, 2, true>(p, s) : launch_wide_t<WK_K5K2, 32, 64, 64, 2, false>(p, s);
         EDMP_K5(32, 64, 64, 2)
     }
     if (cg == 64 && L == 4) {
-        if (karatsuba_l4()) return res ? launch_wide_t<WK_K5K4, 32, 64, 64, 4, true>(p, s) : launch_wide_t<WK_K5K4, 32, 64, 64, 4, false>(p, s);
+        if (form == 4) return res ? launch_wide_t<WK_K5K4, 32, 64, 64, 4, true>(p, s) : launch_wide_t<WK_K5K4, 32, 64, 64, 4, false>(p, s);
         EDMP_K5(32, 64, 64, 4)
     }
     if (cg == 32 && L == 4) {
-        if (karatsuba_l4()) return res ? launch_wide_t<WK_K5K4, 32, 32, 32, 4, true>(p, s) : launch_wide_t<WK_K5K4, 32, 32, 32, 4, false>(p, s);
+        if (form == 4) return res ? launch_wide_t<WK_K5K4, 32, 32, 32, 4, true>(p, s) : launch_wide_t<WK_K5K4, 32, 32, 32, 4, false>(p, s);
         EDMP_K5(32, 32, 32, 4)
     }
     if (cg == 32 && L == 7) { EDMP_K5(32, 32, 32, 7) }
@@ -1376,19 +639,12 @@ static int launch_wrs(const RcbP& p, int kind, int Lin, hipStream_t s) {
 // kernel instance an op launches, spelled as rocprofv3's kernel trace prints it (minus the edmp:: prefix): lets
 // bench.py's per-kernel table be checked line by line against profiles/*_kernel_stats.csv
 static void op_kernel_name(const Op& op, char* out) {
-    static const char* rows_names[] = {"", "rcb_rows_kernel<32, 50, 2, 8>", "rcb_rows_kernel<32, 50, 2, 32>", "rcb_rows_kernel<32, 25, 5, 32>",
-                                       "rcb_rows_kernel<64, 25, 5, 32>", "rcb_rows_kernel<64, 13, 8, 32>", "rcb_rows_kernel<64, 7, 9, 32>"};
-    static const char* blk_names[] = {"", "rcb_block_kernel<32, 50, 2, 8, true>", "", "rcb_block_kernel<32, 50, 2, 32, true>", "rcb_block_kernel<32, 50, 2, 32, false>",
-                                      "rcb_block_kernel<64, 25, 4, 16, true>", "rcb_block_kernel<64, 25, 4, 16, false>", "rcb_block_kernel<64, 13, 4, 32, true>",
-                                      "rcb_block_kernel<64, 13, 4, 32, false>", "rcb_block_kernel<32, 25, 4, 32, true>", "rcb_block_kernel<32, 25, 4, 32, false>"};
-    if (op.kind == OP_RCB && op.rc_rows) snprintf(out, 64, "%s", rows_names[op.rc_rows]);
-    else if (op.kind == OP_RCB || op.kind == OP_WRS) {
+    if (op.kind == OP_RCB || op.kind == OP_WRS) {
         const int cg = op.rc.Cout / 8, ms = wide_ms(op.rc.Cout);
-        const int kind = op.kind == OP_RCB ? ((cg == 64 && op.rc_L == 2 && karatsuba_l2()) ? 3 : (cg >= 32 && op.rc_L == 4 && karatsuba_l4()) ? 4 : 0) : op.wrs_kind;
+        const int kind = op.kind == OP_RCB ? (op.rc_form == 2 ? 3 : op.rc_form == 4 ? 4 : 0) : op.wrs_kind;
         snprintf(out, 64, "wide_conv_kernel<%d, %d, %d, %d, %d, %s>", kind, ms, cg < 32 ? 32 : cg, cg, op.rc_L,
                  (op.kind == OP_RCB && op.rc.res_out) ? "true" : "false");
     }
-    else if (op.kind == OP_BLK) snprintf(out, 64, "%s", blk_names[op.bk_variant]);
     else if (op.kind == OP_LVL) {
         static const char* lv_names[] = {"", "level_kernel<0, 32, 50, 4, 8>", "level_kernel<0, 64, 25, 4, 32>", "level_kernel<1, 64, 13, 4, 256>", "level_kernel<2, 32, 25, 4, 128>"};
         snprintf(out, 64, "%s", lv_names[op.lv_variant]);
@@ -1419,14 +675,32 @@ struct Packer {
     std::vector<float> host;
     bool dry = false;   // layout only: offsets and sizes are computed, nothing is written (loading a packed image)
     size_t total = 0;   // floats packed so far (== host.size() unless dry)
-    size_t add(size_t n) {
+    // signature of the layout actually produced: every tensor's packing form and size, in order (FNV-1a).  The builder's
+    // run-time switches (EDMP_NO_FUSED, EDMP_NO_RESFOLD, EDMP_NO_LEVEL, EDMP_NO_KARATSUBA[4], EDMP_SIDE_STREAM) move
+    // tensors or change their fragment order, several of them without changing the total: the signature is what makes an
+    // image written under one setting unloadable under another
+    uint64_t sig = 1469598103934665603ull;
+    void tag(uint64_t v) {
+        for (int i = 0; i < 8; ++i) {
+            sig ^= (v >> (8 * i)) & 0xff;
+            sig *= 1099511628211ull;
+        }
+    }
+    enum Form : uint64_t { F_CONV = 1, F_CONVT = 2, F_FRAG = 3, F_FRAG_K2 = 4, F_FRAG_K4 = 5, F_RESAMPLE = 6, F_VEC = 7 };
+    size_t add_untagged(size_t n) {
         size_t o = total;
         total += ((n + 3) / 4) * 4;  // keep every tensor 16-byte aligned
         if (!dry) host.resize(total, 0.0f);
         return o;
     }
+    size_t add(size_t n) {
+        tag(n);
+        return add_untagged(n);
+    }
+    int layout_id(int version) const { return (int)(((sig >> 32) ^ sig ^ (uint64_t)version * 2654435761ull) & 0x7fffffff); }
     // Conv1d weight (Cout, Cin, k) -> [tap][Cout][CinP]
     size_t conv(const float* w, int cout, int cin, int k, int cinp) {
+        tag(F_CONV), tag(k), tag(cout), tag(cinp);
         size_t o = add((size_t)k * cout * cinp);
         if (dry) return o;
         for (int co = 0; co < cout; ++co)
@@ -1436,6 +710,7 @@ struct Packer {
     }
     // ConvTranspose1d weight (Cin, Cout, k) -> [tap][Cout][Cin]
     size_t convT(const float* w, int cin, int cout, int k) {
+        tag(F_CONVT), tag(k), tag(cout), tag(cin);
         size_t o = add((size_t)k * cout * cin);
         if (dry) return o;
         for (int ci = 0; ci < cin; ++ci)
@@ -1448,6 +723,8 @@ struct Packer {
     size_t conv_frag(const float* w, const float* wres, int cout, int cin, int cinp, int L) {
         const int sw = wide_ms(cout);
         const int kt0 = (L == 2) ? 1 : 0, ntap = (L == 2) ? 3 : 5, nslab = ntap + (wres ? 1 : 0);
+        tag((L == 4 && sw == 32 && karatsuba_l4()) ? F_FRAG_K4 : (L == 2 && sw == 32 && cout / 8 == 64 && karatsuba_l2()) ? F_FRAG_K2 : F_FRAG);
+        tag(cout), tag(cinp), tag(L), tag(wres ? 1 : 0), tag(sw);
         if (dry) return add((size_t)(cout / sw) * (cinp / (sw == 32 ? 8 : 16)) * ((L == 4 && sw == 32 && karatsuba_l4()) ? 9 + (wres ? 1 : 0) : nslab) * 256);
         std::vector<float> tmp((size_t)6 * cout * cinp, 0.0f);
         for (int co = 0; co < cout; ++co)
@@ -1455,9 +732,11 @@ struct Packer {
                 for (int t = 0; t < 5; ++t) tmp[((size_t)t * cout + co) * cinp + ci] = w[((size_t)co * cin + ci) * 5 + t];
                 if (wres) tmp[((size_t)5 * cout + co) * cinp + ci] = wres[(size_t)co * cin + ci];
             }
-        size_t o = add((size_t)(cout / sw) * (cinp / (sw == 32 ? 8 : 16)) * nslab * 256);
-        if (L == 4 && sw == 32 && karatsuba_l4()) {
-            // nine slots (+ residual) instead of five: the stream is longer than `o` was sized for - re-reserve
+        const bool k4 = L == 4 && sw == 32 && karatsuba_l4();
+        size_t o = k4 ? add_untagged((size_t)(cout / sw) * (cinp / 8) * nslab * 256) : add((size_t)(cout / sw) * (cinp / (sw == 32 ? 8 : 16)) * nslab * 256);
+        if (k4) {
+            // nine slots (+ residual) instead of five: the stream is longer than `o` was sized for - re-reserve (signature
+            // unaffected: the dry path tags the nine-slot size only)
             total = o;
             if (!dry) host.resize(total);
             o = add((size_t)(cout / 32) * (cinp / 8) * (9 + (wres ? 1 : 0)) * 256);
@@ -1468,6 +747,7 @@ struct Packer {
     }
     // strided Conv1d k3 (Cout, Cin, 3) or ConvTranspose1d k4 (Cin, Cout, 4) of a wide level -> fragment stream, slot = tap
     size_t resample_frag(const float* w, int cin, int cout, int k, bool transposed) {
+        tag(F_RESAMPLE), tag(cout), tag(cin), tag(k), tag(transposed ? 1 : 0);
         if (dry) {
             const int sw0 = wide_ms(cout);
             return add((size_t)(cout / sw0) * (cin / (sw0 == 32 ? 8 : 16)) * k * 256);
@@ -1483,6 +763,7 @@ struct Packer {
         return o;
     }
     size_t vec(const float* v, int n) {
+        tag(F_VEC);
         size_t o = add(n);
         if (!dry) memcpy(&host[o], v, sizeof(float) * n);
         return o;
@@ -1526,14 +807,15 @@ extern "C" int64_t edmp_unet_param_count(const edmp_unet_desc* desc) {
     return inventory(*desc).total;
 }
 
-// Layout id of the packed weight image: bump whenever the packing of any kernel family changes (a stale packed file then
-// fails to load instead of feeding a kernel the wrong fragment order)
-static const int kPackLayout = 204;
+// Version of the packing code: bump whenever the packing of any kernel family changes.  The layout id of an image is this
+// version mixed with the signature of the tensor sequence the builder actually produced (Packer::sig): a stale image, or
+// one written under other builder switches, fails to load instead of feeding a kernel the wrong fragment order.
+static const int kPackVersion = 300;
 
 // builds the layer program + device weight image.  packed == nullptr: repack `params` (state-dict order) on the host;
 // otherwise `packed` IS the device image (edmp_unet_read_packed of the same architecture): only the layout is computed
 static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* params, int64_t n_params, int max_batch, const float* packed,
-                      int64_t n_packed) {
+                      int64_t n_packed, int packed_layout) {
     ctx->epoch++;
     EDMP_REQUIRE(desc->n_levels >= 2 && desc->n_levels <= EDMP_MAX_LEVELS, "n_levels out of range");
     EDMP_REQUIRE(desc->input_dim >= 1 && desc->input_dim <= 8, "input_dim must be in 1..8");
@@ -1541,10 +823,9 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
     EDMP_REQUIRE(max_batch >= 1, "max_batch must be positive");
     for (int i = 0; i < desc->n_levels; ++i) EDMP_REQUIRE(desc->dims[i] % 8 == 0 && desc->dims[i] >= 8, "dims must be multiples of 8");
     RawNet inv = inventory(*desc);
-    std::vector<float> zeros;
-    if (packed) {  // the builder only reads `params` for data it writes; give its pointer arithmetic something valid
-        zeros.assign((size_t)inv.total, 0.0f);
-        params = zeros.data();
+    static const float no_params = 0.0f;
+    if (packed) {  // layout-only pass: the builder computes offsets from `params` but never reads through it (Packer::dry)
+        params = &no_params;
         n_params = inv.total;
     }
     EDMP_REQUIRE(inv.total == n_params, "parameter blob has %lld floats, architecture needs %lld", (long long)n_params, (long long)inv.total);
@@ -1553,9 +834,13 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
         unet_destroy(ctx->unet);
         ctx->unet = nullptr;
     }
-    UNet* u = new UNet();
+    // owned here until the build has succeeded: every early return below (argument checks, failed allocations / copies /
+    // launches) releases the weight image and the activation buffers
+    std::unique_ptr<UNet, void (*)(UNet*)> guard(new UNet(), unet_destroy);
+    UNet* u = guard.get();
     u->desc = *desc;
     u->max_batch = max_batch;
+    u->fuse_tail = fuse_tail();
     const int N = desc->horizon;
     const int td = desc->time_dim;
     std::vector<int> dm{desc->input_dim};
@@ -1578,7 +863,7 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
         int tb_off;
         double fn, fe, fd;  // FLOPs per trajectory: nominal | issued | direct form without padding taps (0: same as fe)
         int branch;
-        size_t w2, b2, gamma2, beta2, wr, br;  // OP_BLK; br also = bias of a residual conv folded into an OP_RCB
+        size_t br;  // bias of a residual 1x1 conv folded into an OP_RCB
         int blk;
         int res_out;  // OP_RCB: buffer receiving the folded residual 1x1 conv (-1: none)
         // OP_LVL: offsets of the level's tensors in the packed image, in LevelP order; lv_skip: buffer of the skip output (-1: none)
@@ -1592,6 +877,10 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
     // concatenated time-MLP weights
     std::vector<float> tw_all, tb_all;
     int tb_cursor = 0;
+    auto append = [&](std::vector<float>& v, const float* src, size_t n) {  // layout-only pass: sizes, no reads
+        if (pk.dry) v.resize(v.size() + n, 0.0f);
+        else v.insert(v.end(), src, src + n);
+    };
 
     auto valid_pairs = [](int Lin, int Lout, int k, int stride, int pad, bool tr) {
         long cnt = 0;
@@ -1698,12 +987,9 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
         const RawRCB& r = inv.rcbs[rcb_idx++];
         const int cin_store = x.C + (x2 ? x2->C : 0);
         // conv1 (a residual 1x1 conv folded into the wide fused kernel is packed right behind it, as tap index 5)
-        const bool fold_res = use_fused && r.has_res && getenv("EDMP_NO_RESFOLD") == nullptr && !use_side &&
-                              rcb_supported(r.cout, x.L, x.C, x2 ? x2->C : 0) &&
-                              !((getenv("EDMP_NO_BLOCK") == nullptr) && blk_variant(r.cout, x.L, x.C, x2 ? x2->C : 0, r.has_res));
-        // the wide fused kernel reads its weights as an MFMA fragment stream (wide.hip); everything else as [tap][Cout][Cin]
-        const bool wide = use_fused && rcb_supported(r.cout, x.L, x.C, x2 ? x2->C : 0) &&
-                          !((getenv("EDMP_NO_BLOCK") == nullptr) && blk_variant(r.cout, x.L, x.C, x2 ? x2->C : 0, r.has_res));
+        const bool wide = use_fused && rcb_supported(r.cout, x.L, x.C, x2 ? x2->C : 0);
+        const bool fold_res = wide && r.has_res && getenv("EDMP_NO_RESFOLD") == nullptr && !use_side;
+        // the position-tile kernel reads its weights as an MFMA fragment stream (wide.hip); the generic conv as [tap][Cout][Cin]
         size_t w1 = wide ? pk.conv_frag(params + r.cb[0].w.off, fold_res ? params + r.rw.off : nullptr, r.cout, r.cin, cin_store, x.L)
                          : pk.conv(params + r.cb[0].w.off, r.cout, r.cin, 5, cin_store);
         size_t b1 = pk.vec(params + r.cb[0].b.off, r.cout);
@@ -1713,42 +999,9 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
         size_t g2 = pk.vec(params + r.cb[1].gw.off, r.cout), be2 = pk.vec(params + r.cb[1].gb.off, r.cout);
         int tb_off = tb_cursor;
         tb_cursor += r.cout;
-        tw_all.insert(tw_all.end(), params + r.tw.off, params + r.tw.off + (size_t)r.cout * td);
-        tb_all.insert(tb_all.end(), params + r.tb.off, params + r.tb.off + r.cout);
-        const int bv = (use_fused && getenv("EDMP_NO_BLOCK") == nullptr) ? blk_variant(r.cout, x.L, x.C, x2 ? x2->C : 0, r.has_res) : 0;
-        if (bv) {
-            POp o{};
-            o.kind = OP_BLK;
-            o.blk = bv;
-            o.src1 = x.buf;
-            o.C1 = x.C;
-            o.src2 = x2 ? x2->buf : -1;
-            o.C2 = x2 ? x2->C : 0;
-            o.Lin = x.L;
-            o.Lout = x.L;
-            o.Cout = r.cout;
-            o.w = w1;
-            o.b = b1;
-            o.gamma = g1;
-            o.beta = be1;
-            o.w2 = w2;
-            o.b2 = b2;
-            o.gamma2 = g2;
-            o.beta2 = be2;
-            o.tb_off = tb_off;
-            if (r.has_res) {
-                o.wr = pk.conv(params + r.rw.off, r.cout, r.cin, 1, cin_store);
-                o.br = pk.vec(params + r.rb.off, r.cout);
-            }
-            o.res = r.has_res ? 1 : 0;
-            o.dst = pool.get();
-            const double vp = (double)valid_pairs(x.L, x.L, 5, 1, 2, false);
-            o.fn = 2.0 * x.L * r.cout * 5.0 * ((double)r.cin + r.cout) + (r.has_res ? 2.0 * x.L * r.cout * (double)r.cin : 0.0);
-            o.fe = 2.0 * vp * r.cout * ((double)cin_store + r.cout) + (r.has_res ? 2.0 * x.L * r.cout * (double)cin_store : 0.0);
-            pops.push_back(o);
-            return TH{o.dst, r.cout, x.L};
-        }
-        if (use_fused && (rcb_supported(r.cout, x.L, x.C, x2 ? x2->C : 0) || (rows_variant(r.cout, x.L, x.C, x2 ? x2->C : 0) && rows_variant(r.cout, x.L, r.cout, 0)))) {
+        append(tw_all, params + r.tw.off, (size_t)r.cout * td);
+        append(tb_all, params + r.tb.off, r.cout);
+        if (wide) {
             TH h = emit_fused(x, x2, r.cin, r.cout, w1, b1, g1, be1, -1, tb_off);
             int res_buf;
             int rr_buf = -1;
@@ -1831,8 +1084,8 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
         for (const RawRCB* r : {&r1, &r2}) {  // time-bias table columns, block order
             (r == &r1 ? o.lv_tb1 : o.lv_tb2) = tb_cursor;
             tb_cursor += Cc;
-            tw_all.insert(tw_all.end(), params + r->tw.off, params + r->tw.off + (size_t)Cc * td);
-            tb_all.insert(tb_all.end(), params + r->tb.off, params + r->tb.off + Cc);
+            append(tw_all, params + r->tw.off, (size_t)Cc * td);
+            append(tb_all, params + r->tb.off, Cc);
         }
         o.lv_skip = -1;
         if (want_skip) {
@@ -1853,7 +1106,7 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
         pops.push_back(o);
         return TH{o.dst, Cc, Lout};
     };
-    const bool use_level = use_fused && getenv("EDMP_NO_LEVEL") == nullptr && getenv("EDMP_NO_BLOCK") == nullptr && !use_side;
+    const bool use_level = use_fused && getenv("EDMP_NO_LEVEL") == nullptr && !use_side;
 
     TH x{pool.get(), CP0, N};
     const int x_in_buf = x.buf;
@@ -1953,13 +1206,8 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
         size_t w = pk.conv(params + inv.final_cb.w.off, dm[1], dm[1], 5, dm[1]);
         size_t b = pk.vec(params + inv.final_cb.b.off, dm[1]);
         size_t g = pk.vec(params + inv.final_cb.gw.off, dm[1]), be = pk.vec(params + inv.final_cb.gb.off, dm[1]);
-        TH y;
-        if (use_fused && rows_variant(dm[1], N, x.C, 0)) {
-            y = emit_fused(x, nullptr, dm[1], dm[1], w, b, g, be, -1, -1);
-        } else {
-            y = emit_conv(x, nullptr, dm[1], w, b, dm[1], 5, 1, 2, false, N);
-            emit_gn(y, g, be, -1, -1);
-        }
+        TH y = emit_conv(x, nullptr, dm[1], w, b, dm[1], 5, 1, 2, false, N);
+        emit_gn(y, g, be, -1, -1);
         pool.put(x.buf);
         x = y;
     }
@@ -1977,15 +1225,18 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
     // allocate
     size_t max_lc = (size_t)N * CP0;
     for (auto& o : pops)
-        if (o.kind == OP_CONV || o.kind == OP_RCB || o.kind == OP_BLK || o.kind == OP_WRS || o.kind == OP_LVL) max_lc = std::max(max_lc, (size_t)std::max(o.Lout, o.Lin) * o.Cout);
+        if (o.kind == OP_CONV || o.kind == OP_RCB || o.kind == OP_WRS || o.kind == OP_LVL) max_lc = std::max(max_lc, (size_t)std::max(o.Lout, o.Lin) * o.Cout);
     u->buf_cap = max_lc * (size_t)max_batch;
+    u->layout = pk.layout_id(kPackVersion);
+    if (packed && packed_layout != u->layout) {
+        set_error("packed weight image has layout id %d, this library with the current builder switches packs %d: re-pack from the state dict", packed_layout, u->layout);
+        return EDMP_ERR_ARG;
+    }
     if (packed && (int64_t)pk.total != n_packed) {
-        unet_destroy(u);
         set_error("packed weight image has %lld floats, this architecture / library layout needs %zu", (long long)n_packed, pk.total);
         return EDMP_ERR_ARG;
     }
     if (hipMalloc((void**)&u->wpack, pk.total * sizeof(float)) != hipSuccess) {
-        unet_destroy(u);
         set_error("hipMalloc of %zu weight bytes failed", pk.total * sizeof(float));
         return EDMP_ERR_HIP;
     }
@@ -1994,7 +1245,6 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
     for (int i = 0; i < pool.n; ++i) {
         float* p = nullptr;
         if (hipMalloc((void**)&p, u->buf_cap * sizeof(float)) != hipSuccess) {
-            unet_destroy(u);
             set_error("hipMalloc of activation buffer %d (%zu bytes) failed", i, u->buf_cap * sizeof(float));
             return EDMP_ERR_HIP;
         }
@@ -2030,32 +1280,6 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
             c.bias = u->wpack + o.b;
             c.dst = u->bufs[o.dst];
             c.Cout = o.Cout;
-            op.flops_nominal = o.fn;
-            op.flops_exec = o.fe;
-            u->flops_nominal += o.fn;
-            u->flops_exec += o.fe;
-            op.flops_direct = o.fd > 0 ? o.fd : o.fe;
-            u->flops_direct += op.flops_direct;
-        } else if (o.kind == OP_BLK) {
-            BlkP& c = op.bk;
-            c.src1 = u->bufs[o.src1];
-            c.src2 = o.src2 >= 0 ? u->bufs[o.src2] : nullptr;
-            c.C1 = o.C1;
-            c.C2 = o.C2;
-            c.W1 = u->wpack + o.w;
-            c.b1 = u->wpack + o.b;
-            c.g1 = u->wpack + o.gamma;
-            c.be1 = u->wpack + o.beta;
-            c.tb = nullptr;
-            c.W2 = u->wpack + o.w2;
-            c.b2 = u->wpack + o.b2;
-            c.g2 = u->wpack + o.gamma2;
-            c.be2 = u->wpack + o.beta2;
-            c.Wr = o.res ? u->wpack + o.wr : nullptr;
-            c.br = o.res ? u->wpack + o.br : nullptr;
-            c.dst = u->bufs[o.dst];
-            op.bk_variant = o.blk;
-            op.tb_off = o.tb_off;
             op.flops_nominal = o.fn;
             op.flops_exec = o.fe;
             u->flops_nominal += o.fn;
@@ -2123,7 +1347,7 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
             c.dst = u->bufs[o.dst];
             c.Cout = o.Cout;
             op.rc_L = o.Lin;
-            op.rc_rows = rcb_supported(o.Cout, o.Lin, o.C1, o.C2) ? 0 : rows_variant(o.Cout, o.Lin, o.C1, o.C2);
+            op.rc_form = rcb_form(o.Cout, o.Lin);
             op.tb_off = o.tb_off;
             op.flops_nominal = o.fn;
             op.flops_exec = o.fe;
@@ -2154,23 +1378,22 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
     u->head_b = u->wpack + hb;
     u->head_cin = dm[1];
     for (auto& t : tapr) u->taps.push_back({t.which, u->bufs[t.buf], t.C, t.L});
-    ctx->unet = u;
+    ctx->unet = guard.release();
     return EDMP_OK;
 }
 
 extern "C" int edmp_unet_load(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* params, int64_t n_params, int max_batch) {
     EDMP_REQUIRE(ctx && desc && params, "edmp_unet_load: null argument");
-    return unet_build(ctx, desc, params, n_params, max_batch, nullptr, 0);
+    return unet_build(ctx, desc, params, n_params, max_batch, nullptr, 0, 0);
 }
 
 extern "C" int edmp_unet_load_packed(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* packed, int64_t n_packed, int layout, int max_batch) {
     EDMP_REQUIRE(ctx && desc && packed, "edmp_unet_load_packed: null argument");
-    EDMP_REQUIRE(layout == kPackLayout, "packed weight image has layout %d, this library packs layout %d: re-pack from the state dict", layout, kPackLayout);
-    return unet_build(ctx, desc, nullptr, 0, max_batch, packed, n_packed);
+    return unet_build(ctx, desc, nullptr, 0, max_batch, packed, n_packed, layout);
 }
 
 extern "C" int64_t edmp_unet_packed_size(edmp_ctx* ctx, int* layout) {
-    if (layout) *layout = kPackLayout;
+    if (layout) *layout = (ctx && ctx->unet) ? ctx->unet->layout : 0;
     return (ctx && ctx->unet) ? (int64_t)ctx->unet->wpack_floats : -1;
 }
 
@@ -2234,23 +1457,18 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
             EDMP_HIP_CHECK(hipEventRecord(ev.a, s));
         }
         int rc = EDMP_OK;
-        if (op.kind == OP_BLK) {
-            BlkP p = op.bk;
-            p.B = B;
-            p.tb = trow + op.tb_off;
-            rc = launch_blk(p, op.bk_variant, s);
-        } else if (op.kind == OP_RCB) {
+        if (op.kind == OP_RCB) {
             RcbP p = op.rc;
             p.B = B;
             p.add_tb = op.tb_off >= 0 ? trow + op.tb_off : nullptr;
             EDMP_REQUIRE(!(p.add_tb && p.add_res), "fused conv block: a launch adds the time bias (conv1) or the residual (conv2), not both");
-            rc = op.rc_rows ? launch_rows(p, op.rc_rows, s) : launch_rcb(p, op.rc_L, s);
+            rc = launch_rcb(p, op.rc_L, op.rc_form, s);
         } else if (op.kind == OP_LVL) {
             LevelP p = op.lv;
             p.B = B;
             p.tb1 = trow + op.lv_tb1;
             p.tb2 = trow + op.lv_tb2;
-            if (tail && tail_done && op.lv_variant == 4 && op_index + 1 == (int)u->prog.size() && u->head_cin == 32 && tail->N == u->desc.horizon && tail->C <= 8 && p.out == u->h_last && fuse_tail()) {
+            if (tail && tail_done && op.lv_variant == 4 && op_index + 1 == (int)u->prog.size() && u->head_cin == 32 && tail->N == u->desc.horizon && tail->C <= 8 && p.out == u->h_last && u->fuse_tail) {
                 p.tail = *tail;
                 p.tail.on = 1;
                 p.tail.w = u->head_w;
@@ -2299,7 +1517,8 @@ int prof_fold(edmp_ctx* ctx) {
         EDMP_HIP_CHECK(hipEventElapsedTime(&ms, e.a, e.b));
         p.conv_ms += ms;
         if (e.op < 0) {  // whole-program bracket: counts every launch of the program
-            for (const Op& op : ctx->unet->prog) p.conv_launches += (op.kind != OP_GN) ? 1 : 0;
+            if (ctx->unet)
+                for (const Op& op : ctx->unet->prog) p.conv_launches += (op.kind != OP_GN) ? 1 : 0;
         } else {
             p.conv_launches += 1;
         }

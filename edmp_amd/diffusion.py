@@ -156,10 +156,19 @@ class Diffusion:
                 raise ValueError("sharded runs take an explicit noise array (this rank's rows of the global stream)")
             sumsq = self.sumsq_tensor()
 
+            import time as _time
+
+            stats = self.hook_stats = dict(calls=0, total_s=0.0, max_s=0.0)  # host time spent in the hook (GIL + collective enqueue)
+
             def _hook(_user, _stream, _ptr):
                 try:
+                    t0 = _time.perf_counter()
                     with torch.cuda.stream(ctx.stream):  # RCCL orders itself after the gradient kernels / before step_b
                         allreduce(sumsq)
+                    dt = _time.perf_counter() - t0
+                    stats["calls"] += 1
+                    stats["total_s"] += dt
+                    stats["max_s"] = max(stats["max_s"], dt)
                     return 0
                 except Exception as exc:  # surfaced by the C side as EDMP_ERR_STATE
                     self._hook_error = exc

@@ -42,16 +42,23 @@ class TemporalUNet:
             # packing layout, and is not older than the state-dict checkpoint)
             pk = weights.read_packed(os.path.join(model_name, weights.PACKED_NAME))
             ck = os.path.join(model_name, "weights_latest.pt")
-            layout = C.c_int()
-            self.ctx.lib.edmp_unet_packed_size(self.ctx.h, C.byref(layout))
-            if (pk is not None and pk["layout"] == layout.value and (pk["input_dim"], pk["time_dim"], pk["dims"], pk["horizon"], pk["T"]) ==
+            if (pk is not None and (pk["input_dim"], pk["time_dim"], pk["dims"], pk["horizon"], pk["T"]) ==
                     (self.input_dim, self.time_dim, self.dims, self.horizon, self.T)
                     and (not os.path.exists(ck) or os.path.getmtime(os.path.join(model_name, weights.PACKED_NAME)) >= os.path.getmtime(ck))):
+                # the image's layout id covers the library's packing version AND the layout the builder produces under the
+                # current run-time switches (EDMP_NO_*): edmp_unet_load_packed recomputes it and refuses a mismatch - then
+                # the state-dict checkpoint is loaded instead
                 self._packed = pk
-                self.losses = np.load(os.path.join(model_name, "losses.npy")) if os.path.exists(os.path.join(model_name, "losses.npy")) else np.array([])
-                print("Loaded Model at " + str(self.losses.size) + " epochs")
-                self._bind()
-                return
+                try:
+                    self._bind()
+                except _capi.EdmpError:
+                    self._packed = None
+                    if not os.path.exists(ck):
+                        raise
+                else:
+                    self.losses = np.load(os.path.join(model_name, "losses.npy")) if os.path.exists(os.path.join(model_name, "losses.npy")) else np.array([])
+                    print("Loaded Model at " + str(self.losses.size) + " epochs")
+                    return
         if state_dict is None:
             if model_name is not None and os.path.exists(model_name):
                 state_dict = weights.load_checkpoint_dir(model_name)

@@ -229,10 +229,15 @@ def main():
         save(f"g8_unet_{tag}", seed=np.array(seed), dims=np.array(dims), x=xb.numpy(), **outs, **{"trace_" + k: v.numpy() for k, v in tr.items()})
 
     # ---------------------------------------------------------------- G9 teacher-forced traces of denoise_guided
-    print("G9 denoise_guided traces (tiny UNet)")
-    net_tiny, sd_tiny = nets["tiny"]
+    # three runs on the tiny UNet + one on the FULL dims=(32,64,128,256,512,512) network (B = 6, guides 1 / 10 / 11: iv, sv,
+    # sv + grad_norm), so that a reference-generated trace also passes through the kernels that are benchmarked (the
+    # position-tile / whole-level kernels have no instance for the tiny widths).  Weights come from the seeded generator
+    # (edmp_amd.weights.init_state_dict), so the fixture holds states only.
+    print("G9 denoise_guided traces (tiny UNet x3, full UNet x1)")
     keep = [255, 254, 253, 200, 129, 128, 100, 51, 50, 8, 7, 6, 5, 4, 3, 2, 1]
-    for tag, guides, bpg, seed in (("c1_g1_b4", [1], 4, 21), ("c3_g6_b12", six, 2, 22), ("mixed_b12", mixed, 2, 23)):
+    for tag, guides, bpg, seed, which in (("c1_g1_b4", [1], 4, 21, "tiny"), ("c3_g6_b12", six, 2, 22, "tiny"), ("mixed_b12", mixed, 2, 23, "tiny"),
+                                          ("full_b6", [1, 10, 11], 2, 24, "full")):
+        net_tiny, sd_tiny = nets[which]
         cfgs = ref_guide_cfgs(guides, bpg)
         B = cfgs["total_batch_size"]
         rgd = refg.IntersectionVolumeGuide(scene, "cpu", cfgs, B)
@@ -248,6 +253,8 @@ def main():
         check(f"G10.{tag} row volumes", og9.row_swept_volumes(START, GOAL, X_r).numpy(), vols_r)
         check(f"G10.{tag} best", og9.choose_best_trajectory(START, GOAL, X_r), best_r)
         arrs = dict(scene=scene, guides=np.array(guides), bpg=np.array(bpg), seed=np.array(seed), start=START, goal=GOAL, X_final=X_r, row_volumes=vols_r, best=best_r, best_index=np.array(int(np.argmin(vols_r))), steps=np.array(keep))
+        if which != "tiny":
+            arrs.update(unet_dims=np.array(FULL_DIMS), unet_seed=np.array(6))
         for t in keep:
             s = trace[t]
             arrs[f"x_in_{t}"] = s["x_in"]

@@ -142,8 +142,9 @@ def test_fused_and_unfused_paths_agree(monkeypatch):
     sd = W.init_state_dict(12, 7, 32, FULL_DIMS)
     x = torch.tensor(np.random.RandomState(4).standard_normal((33, 7, 50)), dtype=torch.float32)
     a = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, state_dict=sd, max_batch=33)(x, torch.tensor([9.0])).cpu().numpy()
-    # every program-builder switch gives the same network: no residual fold, no whole-block kernels, no fusion at all
-    for env in ("EDMP_NO_RESFOLD", "EDMP_NO_BLOCK", "EDMP_NO_FUSED"):
+    # every program-builder switch gives the same network: no residual fold, no whole-level kernels (the 32/64-channel
+    # levels on the generic conv + GroupNorm kernels), no fusion at all (the generic fallback everywhere)
+    for env in ("EDMP_NO_RESFOLD", "EDMP_NO_LEVEL", "EDMP_NO_FUSED"):
         monkeypatch.setenv(env, "1")
         b = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, state_dict=sd, max_batch=33)(x, torch.tensor([9.0])).cpu().numpy()
         monkeypatch.delenv(env)
@@ -276,14 +277,24 @@ def test_guide_edge_sizes_vs_oracle(oracle, n_obstacles, bpg, guides):
     assert maxabs(va, np.asarray(vb)) <= 2e-5 and ia == int(np.argmin(np.asarray(vb)))
 
 
-@pytest.mark.parametrize("tag", ["c1_g1_b4", "c3_g6_b12", "mixed_b12"])
+@pytest.mark.parametrize("tag", ["c1_g1_b4", "c3_g6_b12", "mixed_b12", "full_b6"])
 def test_teacher_forced_steps(golden, tiny_net, tag):
-    """Every kept step of the reference's own run: feed its X_t and z_t, compare eps, posterior, gradient, X_{t-1}."""
+    """Every kept step of the reference's own run: feed its X_t and z_t, compare eps, posterior, gradient, X_{t-1}.
+    `full_b6` is a run of the reference on the FULL dims=(32,64,128,256,512,512) network: its steps pass through the
+    position-tile / whole-level kernels (wide_conv_kernel, level_kernel incl. the Karatsuba forms) that bench.py times."""
     from edmp_amd.diffusion import Diffusion
     from edmp_amd.guide import IntersectionVolumeGuide
 
-    net, _ = tiny_net
     g = golden(f"g9_trace_{tag}")
+    if "unet_dims" in g.files:
+        from edmp_amd import weights as W
+        from edmp_amd.temporalunet import TemporalUNet
+
+        dims = tuple(int(d) for d in g["unet_dims"])
+        assert dims == FULL_DIMS
+        net = TemporalUNet(None, 7, 32, DEV, dims=dims, state_dict=W.init_state_dict(int(g["unet_seed"]), 7, 32, dims), max_batch=8)
+    else:
+        net, _ = tiny_net
     cfgs = cfgs_for(g["guides"], g["bpg"])
     B = cfgs["total_batch_size"]
     guide = IntersectionVolumeGuide(g["scene"], DEV, cfgs, B)
@@ -927,8 +938,10 @@ def _nccl_worker(rank, world, port, q):
     import torch.distributed as dist
 
     try:
-        torch.cuda.set_device(0)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+        # one GPU per rank when the box has them (rank -> cuda:rank); on a one-GPU box every rank lands on cuda:0
+        DEV = f"cuda:{rank % max(torch.cuda.device_count(), 1)}"  # noqa: N806 - shadows the module constant for this worker
+        torch.cuda.set_device(torch.device(DEV))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(DEV))
         from edmp_amd import dist as ED
         from edmp_amd import scenes
         from edmp_amd import weights as W
@@ -937,11 +950,11 @@ def _nccl_worker(rank, world, port, q):
         from edmp_amd.temporalunet import TemporalUNet
 
         # device-tensor collectives of the data path: scalar all-reduce, end-of-sampling all-gather + broadcast
-        x = torch.full((1,), 2.5 + rank, dtype=torch.float64, device="cuda:0")
+        x = torch.full((1,), 2.5 + rank, dtype=torch.float64, device=DEV)
         ED.allreduce_sum_(x, always=True)
         torch.cuda.synchronize()
         traj = np.full((7, 50), float(rank))
-        best = ED.gather_best(3.0 - rank, 5 + rank, traj, True, device="cuda:0", always=True)
+        best = ED.gather_best(3.0 - rank, 5 + rank, traj, True, device=DEV, always=True)
         # the sharded reverse loop with the RCCL all-reduce enqueued from inside the device-resident loop
         cfgs = cfgs_for([1, 11, 18, 10], 3)
         Btot = cfgs["total_batch_size"]
@@ -1010,18 +1023,78 @@ def test_rccl_branch_world_size_one():
     assert np.array_equal(X, Xref)
 
 
-def test_rccl_two_ranks_on_one_gpu_or_skip():
-    """Two RCCL ranks need two GPUs; on a one-GPU box RCCL refuses the duplicate device - then this test records the
-    reason and skips.  With >= 2 GPUs visible it would run the sharded loop over a real xGMI all-reduce."""
-    if torch.cuda.device_count() >= 2:
-        pytest.skip("two-GPU variant is covered by scripts/run_scale.sh on the multi-GPU lease (ranks pinned per device)")
-    out = _spawn(_nccl_worker, 2, timeout=120)
+def test_rccl_two_ranks():
+    """Two RCCL ranks, the sharded loop over a real all-reduce.  With >= 2 GPUs visible each rank takes its own device
+    (rank -> cuda:rank, xGMI between them) and the result must equal the single-process run of the whole batch to 1e-9
+    (only the f64 summation order of sum(g^2) differs).  On a one-GPU box RCCL refuses the duplicate device: the reason is
+    recorded and the test skips."""
+    from edmp_amd import scenes
+    from edmp_amd import weights as W
+    from edmp_amd.diffusion import Diffusion
+    from edmp_amd.guide import IntersectionVolumeGuide
+    from edmp_amd.temporalunet import TemporalUNet
+
+    multi = torch.cuda.device_count() >= 2
+    out = _spawn(_nccl_worker, 2, timeout=300 if multi else 120)
     errs = [o for o in out if o[0] == "error"]
-    if errs:
+    if errs and not multi:
         pytest.skip(f"RCCL refuses two ranks on one GPU: {errs[0][2][:200]}")
+    assert not errs, errs
     cfgs = cfgs_for([1, 11, 18, 10], 3)
+    B = cfgs["total_batch_size"]
     assert [o[0] for o in out] == ["ok", "ok"] and out[0][2] == out[1][2] == 6.0  # 2.5 + 3.5
-    assert np.concatenate([out[0][-1], out[1][-1]]).shape[0] == cfgs["total_batch_size"]
+    assert (out[0][3], out[0][4], out[0][5], out[0][6]) == (out[1][3], out[1][4], out[1][5], out[1][6]) == (1, 6, 2.0, 1.0)  # rank 1 holds the smaller volume
+    Xsh = np.concatenate([out[0][-1], out[1][-1]])
+    assert Xsh.shape[0] == B and (out[0][7], out[0][8], out[1][7], out[1][8]) == (0, B // 2, B // 2, B)
+    net = TemporalUNet(None, 7, 32, DEV, dims=TINY_DIMS, state_dict=W.init_state_dict(5, 7, 32, TINY_DIMS), max_batch=B)
+    guide = IntersectionVolumeGuide(scenes.random_scene(7, 8), DEV, cfgs, B)
+    Xref = Diffusion(T, DEV).denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=scenes.DEFAULT_START, goal=scenes.DEFAULT_GOAL,
+                                            noise=noise_for(41, B), t_stop=T - 10)
+    assert maxabs(Xsh, Xref) <= 1e-9, maxabs(Xsh, Xref)
+
+
+def _run_bench_under_torchrun(extra, nproc=2, timeout=900):
+    """bench.py launched exactly as the driver's scaling run does (python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...); on a box with fewer GPUs than
+    ranks the ranks share the device over gloo (EDMP_DIST_BACKEND=gloo), with enough GPUs the real RCCL path runs."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    from tests.conftest import ROOT
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.device_count() < nproc:
+        env["EDMP_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline", *extra]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints exactly one JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mode", ["replicas", "logical_batch"])
+def test_bench_two_ranks_under_torchrun(mode):
+    """the driver's N > 1 launch path of bench.py (BASELINE configs 4 and 5; reference: one process per device,
+    /root/reference/benchmark/cfgs/cfg2.yaml:2,14): plain row-sharded replicas with the end-of-sampling gather, and one
+    logical batch of 2048 rows over the 8-guide ensemble with the per-guided-step all-reduce inside the device loop."""
+    import math
+
+    extra = [] if mode == "replicas" else ["--logical-batch", "--guides", "1,2,3,4,5,10,11,13"]
+    d = _run_bench_under_torchrun(extra)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2048 and d["steps"] == 1 and d["scaling"] == "weak"
+    assert math.isfinite(d["value"]) and d["value"] > 0 and abs(d["value"] - 2048 * 255 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["success_proxy"]["rows"] == 2048 and 0 <= d["success_proxy"]["rows_ok"] <= 2048
+    assert ("logical batch" in d["config"]["parallelism"]) == (mode == "logical_batch")
 
 
 def test_allreduce_hook_inside_the_device_loop(tiny_net):
@@ -1149,9 +1222,10 @@ def test_resident_slots_keep_alternating_objects_loaded(tiny_net):
     assert np.array_equal(guides[0].cost(q, 0).cpu().numpy(), ref[0]) and tuple(many[0].cost(q, 0).shape) == (4, 48, 9 * 3)
 
 
-def test_packed_weight_image_round_trip(tmp_path):
+def test_packed_weight_image_round_trip(tmp_path, monkeypatch):
     """TemporalUNet.pack(): the device weight image written next to the checkpoint loads with one mmap + one copy and
-    gives bit-identical outputs; a stale image (older than the checkpoint, other architecture) is ignored."""
+    gives bit-identical outputs; a stale image (older than the checkpoint, other architecture, other builder switches) is
+    ignored."""
     import os
     import time as _time
 
@@ -1175,6 +1249,18 @@ def test_packed_weight_image_round_trip(tmp_path):
     assert b._packed is not None and b._flat is None
     assert np.array_equal(b(x, t).cpu().numpy(), ya)
     print(f"load from state dict {t_sd:.2f} s, from the packed image {t_pk:.2f} s")
+    # builder switches that move tensors inside the image WITHOUT changing its size: the layout id covers the
+    # layout actually produced, so the image is refused and the state dict is loaded instead - same network, other kernels
+    for env in ("EDMP_NO_RESFOLD", "EDMP_NO_KARATSUBA", "EDMP_NO_LEVEL"):
+        monkeypatch.setenv(env, "1")
+        e = TemporalUNet(d, 7, 32, DEV, dims=FULL_DIMS, max_batch=8)
+        monkeypatch.delenv(env)
+        assert e._packed is None and e._flat is not None, env
+        ye = e(x, t).cpu().numpy()
+        assert rmse(ye, ya) <= 1e-5 and not np.array_equal(ye, ya), env
+        lay = C_int()
+        e.ctx.lib.edmp_unet_packed_size(e.ctx.h, byref(lay))
+        assert lay.value != b._packed["layout"], env
     # another architecture in the same directory: the image is ignored, the state dict decides (and fails on shapes)
     with pytest.raises((ValueError, KeyError)):
         TemporalUNet(d, 7, 32, DEV, dims=TINY_DIMS, max_batch=8)
@@ -1185,3 +1271,58 @@ def test_packed_weight_image_round_trip(tmp_path):
     c = TemporalUNet(d, 7, 32, DEV, dims=FULL_DIMS, max_batch=8)
     assert c._packed is None and not np.array_equal(c(x, t).cpu().numpy(), ya)
     b.save()  # a model constructed from the image can still write the reference's state-dict format
+
+
+def _adversarial_state_dict(kind, seed):
+    """the seeded full-size weights with the k5 Conv1dBlock filters (blocks.py:13-34) reshaped into cases that stress the
+    Karatsuba forms w2 (x0 + x1) + (w3 - w2) x1 of the L = 2 / L = 4 levels (wide.hip): their rounding error scales with
+    |w2| |x|, not with the result."""
+    from edmp_amd import weights as W
+
+    sd = W.init_state_dict(seed, 7, 32, FULL_DIMS)
+    rs = np.random.RandomState(seed + 100)
+    for name, w in sd.items():
+        if not (name.endswith(".block.0.weight") and w.ndim == 3 and w.shape[2] == 5):
+            continue
+        w = w.astype(np.float64)
+        if kind == "centre":      # a trained smoothing filter: centre tap dominant
+            w[:, :, 2] *= 30.0
+        elif kind == "heavy":     # heavy-tailed taps (Student t, 2 degrees of freedom)
+            w *= np.clip(np.abs(rs.standard_t(2, w.shape)), 0.05, 50.0)
+        elif kind == "equal":     # w1 ~ w2 ~ w3: the differences w3 - w2, w1 - w2 cancel catastrophically
+            for k in (1, 3):
+                w[:, :, k] = w[:, :, 2] * (1.0 + 1e-4 * rs.standard_normal(w.shape[:2]))
+        elif kind == "scale":     # per-output-channel scale spread 1e-3 .. 1e3
+            w *= (10.0 ** rs.uniform(-3, 3, (w.shape[0], 1, 1)))
+        else:
+            raise ValueError(kind)
+        sd[name] = w.astype(np.float32)
+    return sd
+
+
+@pytest.mark.parametrize("kind", ["centre", "heavy", "equal", "scale"])
+def test_karatsuba_forms_with_adversarial_weights(oracle, monkeypatch, kind):
+    """Full-size forward vs the oracle with weight distributions that are hostile to the bilinear (Karatsuba) forms, at the
+    UNCHANGED gates of the random-init test (rmse 2e-5, max 2e-4); the error of the Karatsuba build, of the direct-form
+    build (EDMP_NO_KARATSUBA=1) and of torch's own float32 forward are measured against a float64 evaluation of the same
+    network and printed.  Conv1dBlock: /root/reference/diffusion/models/blocks.py:13-34."""
+    from edmp_amd.temporalunet import TemporalUNet
+
+    sd = _adversarial_state_dict(kind, 31)
+    B = 37
+    x = torch.tensor(np.random.RandomState(6).standard_normal((B, 7, 50)) * 1.5, dtype=torch.float32)
+    t = torch.tensor([123.0])
+    with torch.no_grad():
+        ref32 = oracle.unet_forward({k: torch.from_numpy(v) for k, v in sd.items()}, x, t).numpy()
+        ref64 = oracle.unet_forward({k: torch.from_numpy(v).double() for k, v in sd.items()}, x.double(), t.double()).numpy()
+    kar = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, state_dict=sd, max_batch=B)(x, t).cpu().numpy()
+    monkeypatch.setenv("EDMP_NO_KARATSUBA", "1")
+    direct = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, state_dict=sd, max_batch=B)(x, t).cpu().numpy()
+    monkeypatch.delenv("EDMP_NO_KARATSUBA")
+    e_k, e_d, e_t = rmse(kar, ref64), rmse(direct, ref64), rmse(ref32, ref64)
+    print(f"\n[karatsuba/{kind}] rms(eps) {float(np.sqrt(np.mean(ref64 ** 2))):.3g}; rmse vs f64: karatsuba {e_k:.3e}, direct {e_d:.3e}, torch f32 {e_t:.3e}; "
+          f"ratio karatsuba/direct {e_k / max(e_d, 1e-30):.2f}; vs the f32 oracle: rmse {rmse(kar, ref32):.3e} max {maxabs(kar, ref32):.3e}")
+    assert not np.array_equal(kar, direct)  # the switch really selects another kernel form
+    assert rmse(kar, ref32) <= 2e-5 and maxabs(kar, ref32) <= 2e-4, (kind, rmse(kar, ref32), maxabs(kar, ref32))
+    assert rmse(direct, ref32) <= 2e-5 and maxabs(direct, ref32) <= 2e-4, (kind, rmse(direct, ref32), maxabs(direct, ref32))
+    assert e_k <= 3.0 * max(e_d, e_t), (kind, e_k, e_d, e_t)
