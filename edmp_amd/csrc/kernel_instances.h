@@ -37,6 +37,10 @@
     X(8, LV_DOWN, 32, 50, 4, 8)        \
     X(9, LV_DOWN, 64, 25, 4, 32)       \
     X(10, LV_UP, 64, 13, 4, 256)       \
-    X(11, LV_UP_FINAL, 32, 25, 4, 128)
+    X(11, LV_UP_FINAL, 32, 25, 4, 128) \
+    X(12, LV_DOWN, 32, 50, 2, 8)       \
+    X(13, LV_DOWN, 64, 25, 2, 32)      \
+    X(14, LV_UP, 64, 13, 2, 256)       \
+    X(15, LV_UP_FINAL, 32, 25, 2, 128)
 
-#define EDMP_KERNEL_SHARDS 12
+#define EDMP_KERNEL_SHARDS 16

@@ -28,6 +28,10 @@ namespace edmp {
 #define EDMP_SHARD_9(...)
 #define EDMP_SHARD_10(...)
 #define EDMP_SHARD_11(...)
+#define EDMP_SHARD_12(...)
+#define EDMP_SHARD_13(...)
+#define EDMP_SHARD_14(...)
+#define EDMP_SHARD_15(...)
 #if EDMP_SHARD == 0
 #undef EDMP_SHARD_0
 #define EDMP_SHARD_0(...) __VA_ARGS__
@@ -64,6 +68,18 @@ namespace edmp {
 #elif EDMP_SHARD == 11
 #undef EDMP_SHARD_11
 #define EDMP_SHARD_11(...) __VA_ARGS__
+#elif EDMP_SHARD == 12
+#undef EDMP_SHARD_12
+#define EDMP_SHARD_12(...) __VA_ARGS__
+#elif EDMP_SHARD == 13
+#undef EDMP_SHARD_13
+#define EDMP_SHARD_13(...) __VA_ARGS__
+#elif EDMP_SHARD == 14
+#undef EDMP_SHARD_14
+#define EDMP_SHARD_14(...) __VA_ARGS__
+#elif EDMP_SHARD == 15
+#undef EDMP_SHARD_15
+#define EDMP_SHARD_15(...) __VA_ARGS__
 #else
 #error "EDMP_SHARD out of range"
 #endif

@@ -68,7 +68,7 @@ __device__ __forceinline__ float lv_group_sum(float x) {
 }
 
 template <int MODE, int C, int L, int SB, int CIN>
-__global__ __launch_bounds__(256) void level_kernel(const float* a_src1, const float* a_src2, const float* a_w11, int a_C1, int a_C2, int a_B, LevelP pr) {
+__global__ __launch_bounds__(256, (SB <= 2 ? 2 : 1)) void level_kernel(const float* a_src1, const float* a_src2, const float* a_w11, int a_C1, int a_C2, int a_B, LevelP pr) {
     // (leading scalar arguments = what the input staging needs: preloaded into SGPRs at wave launch, see wide_conv_kernel)
     LevelP p = pr;
     p.src1 = a_src1, p.src2 = a_src2, p.w11 = a_w11, p.C1 = a_C1, p.C2 = a_C2, p.B = a_B;

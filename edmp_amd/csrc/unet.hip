@@ -126,6 +126,7 @@ struct Op {
     RcbP rc;
     LevelP lv;    // OP_LVL: a whole level
     int lv_variant;
+    int lv_sb;    // samples per workgroup (level_sb, frozen at build time)
     int lv_tb1, lv_tb2;  // offsets of the two blocks' time biases in the time-bias row
     int rc_L;     // OP_RCB / OP_WRS: input positions
     int rc_form;  // OP_RCB: 0 direct | 2 / 4 Karatsuba form at L = 2 / 4 (decided when the model was built)
@@ -603,12 +604,25 @@ static int level_variant(int mode, int C, int L, int c1, int c2) {
     return 0;
 }
 static int level_kx(int variant) { return variant == 1 ? 16 : variant == 2 ? 32 : variant == 3 ? 256 : 128; }
-static int launch_level(const LevelP& p, int variant, hipStream_t s) {
-    switch (variant) {
-        case 1: return launch_level_t<LV_DOWN, 32, 50, 4, 8>(p, s);
-        case 2: return launch_level_t<LV_DOWN, 64, 25, 4, 32>(p, s);
-        case 3: return launch_level_t<LV_UP, 64, 13, 4, 256>(p, s);
-        case 4: return launch_level_t<LV_UP_FINAL, 32, 25, 4, 128>(p, s);
+// samples per workgroup of the level kernels, per variant: 4 = one workgroup per CU at B = 1024; 2 = two co-resident
+// workgroups per CU (two waves per SIMD: one workgroup's GroupNorm / Mish epilogues, barriers and staging run under the other's
+// MFMAs).  EDMP_LEVEL_SB=<d1><d2><d3><d4> (digits 2 / 4 for variants 1..4) overrides at model-build time (A/B runs).
+static int level_sb(int variant) {
+    static const char kDefault[] = "4444";
+    const char* e = getenv("EDMP_LEVEL_SB");
+    const char* t = (e && strlen(e) == 4) ? e : kDefault;
+    return t[variant - 1] == '2' ? 2 : 4;
+}
+static int launch_level(const LevelP& p, int variant, int sb, hipStream_t s) {
+    switch (variant * 10 + sb) {
+        case 14: return launch_level_t<LV_DOWN, 32, 50, 4, 8>(p, s);
+        case 24: return launch_level_t<LV_DOWN, 64, 25, 4, 32>(p, s);
+        case 34: return launch_level_t<LV_UP, 64, 13, 4, 256>(p, s);
+        case 44: return launch_level_t<LV_UP_FINAL, 32, 25, 4, 128>(p, s);
+        case 12: return launch_level_t<LV_DOWN, 32, 50, 2, 8>(p, s);
+        case 22: return launch_level_t<LV_DOWN, 64, 25, 2, 32>(p, s);
+        case 32: return launch_level_t<LV_UP, 64, 13, 2, 256>(p, s);
+        case 42: return launch_level_t<LV_UP_FINAL, 32, 25, 2, 128>(p, s);
     }
     set_error("no whole-level kernel variant %d", variant);
     return EDMP_ERR_STATE;
@@ -646,8 +660,8 @@ static void op_kernel_name(const Op& op, char* out) {
                  (op.kind == OP_RCB && op.rc.res_out) ? "true" : "false");
     }
     else if (op.kind == OP_LVL) {
-        static const char* lv_names[] = {"", "level_kernel<0, 32, 50, 4, 8>", "level_kernel<0, 64, 25, 4, 32>", "level_kernel<1, 64, 13, 4, 256>", "level_kernel<2, 32, 25, 4, 128>"};
-        snprintf(out, 64, "%s", lv_names[op.lv_variant]);
+        static const char* lv_fmt[] = {"", "level_kernel<0, 32, 50, %d, 8>", "level_kernel<0, 64, 25, %d, 32>", "level_kernel<1, 64, 13, %d, 256>", "level_kernel<2, 32, 25, %d, 128>"};
+        snprintf(out, 64, lv_fmt[op.lv_variant], op.lv_sb);
     }
     else if (op.kind == OP_CONV) {
         const int kc = pick_kc(op.cv);
@@ -1304,6 +1318,7 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
             c.skip_out = o.lv_skip >= 0 ? u->bufs[o.lv_skip] : nullptr;
             c.out = u->bufs[o.dst];
             op.lv_variant = o.lv_variant;
+            op.lv_sb = level_sb(o.lv_variant);
             op.lv_tb1 = o.lv_tb1;
             op.lv_tb2 = o.lv_tb2;
             op.flops_nominal = o.fn;
@@ -1475,7 +1490,7 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
                 p.tail.bias = u->head_b;
                 *tail_done = true;
             }
-            rc = launch_level(p, op.lv_variant, s);
+            rc = launch_level(p, op.lv_variant, op.lv_sb, s);
         } else if (op.kind == OP_WRS) {
             RcbP p = op.rc;
             p.B = B;

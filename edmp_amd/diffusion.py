@@ -202,33 +202,66 @@ class Diffusion:
             # enqueued at once, so the host RNG (edmp_amd.nprng: ~0.9 ms per step for 1024 rows on 16 cores; NumPy itself needs 3.3-4 ms) runs while the GPU
             # denoises the previous chunk.  The numbers and their order are those of one big standard_normal call.
             guided = 1 if guide is not None else 0
-            # chunk plan: (steps, carries X_T); the first chunk is short so that the GPU starts sooner
-            plan, t_left, first = [], self.T - int(t_stop), True
+            # chunk plan: (steps, carries X_T).  The first chunks are short and double (1, 2, 4, ... steps) so that the GPU
+            # starts after ONE step's worth of draws and the host gets ahead of it geometrically.
+            plan, t_left, first, k = [], self.T - int(t_stop), True, 1
             while t_left > 0:
-                k = min(int(chunk_steps) if not first else max(1, int(chunk_steps) // 4), t_left)
-                plan.append((k, first))
-                t_left -= k
+                kk = min(k, int(chunk_steps), t_left)
+                plan.append((kk, first))
+                t_left -= kk
                 first = False
-            shape = lambda k, f: (k + (1 if f else 0), batch_size, num_channels, traj_len)  # noqa: E731
-            # the draws run in ONE background thread (the C helper releases the GIL), strictly in order, so chunk i+1 is
-            # being drawn while this thread uploads chunk i and enqueues its ~1000 kernel launches
-            from concurrent.futures import ThreadPoolExecutor
+                k *= 2
+            per_step = batch_size * num_channels * traj_len
+            # The draws go straight into PINNED host memory (a ring of staging buffers owned by the context), so the upload is
+            # one asynchronous DMA on the copy stream - no pageable-memory staging copy on a host core, which the draw threads
+            # need.  A staging buffer is reused only after the copy out of it has completed (event).  The draws run in ONE
+            # background thread (the C helper releases the GIL), strictly in order, with two threads fewer than the CPU quota
+            # (nprng.draw_threads): chunk i+1 is drawn while this thread uploads chunk i and enqueues its kernel launches.
+            ring = ctx.pinned_ring(3, (int(chunk_steps) + 1) * per_step)
+            nthr = nprng.draw_threads()
+
+            import os as _os
+            import time as _time
+
+            trace = self.noise_trace = [] if _os.environ.get("EDMP_NOISE_TRACE") else None  # per chunk: host timestamps (debug)
+            t_call = _time.perf_counter()
+
+            def draw(i):
+                kk, f = plan[i]
+                slot = ring[i % len(ring)]
+                t0 = _time.perf_counter()
+                if slot["event"] is not None:
+                    slot["event"].synchronize()  # the previous upload out of this buffer is done
+                t1 = _time.perf_counter()
+                n = (kk + (1 if f else 0)) * per_step
+                nprng.standard_normal((n,), nthreads=nthr, out=slot["np"][:n])
+                if trace is not None:
+                    trace.append(("draw", i, kk, t0 - t_call, t1 - t_call, _time.perf_counter() - t_call))
+                return slot, n
 
             t_hi, keep = self.T, []
-            with ThreadPoolExecutor(max_workers=1) as pool:
-                pending = pool.submit(nprng.standard_normal, shape(*plan[0])) if plan else None
-                for i, (k, f) in enumerate(plan):
-                    z = pending.result()
-                    pending = pool.submit(nprng.standard_normal, shape(*plan[i + 1])) if i + 1 < len(plan) else None
-                    zd = ctx.to_dev_overlapped(z, torch.float64)  # copy stream: the upload runs beside the previous chunk's kernels
+            pool = ctx.draw_pool()  # ONE long-lived draw thread per context: its OpenMP team stays alive (and warm) between scenes
+            if True:
+                pending = pool.submit(draw, 0) if plan else None
+                for i, (kk, f) in enumerate(plan):
+                    ta = _time.perf_counter()
+                    slot, n = pending.result()
+                    tb = _time.perf_counter()
+                    pending = pool.submit(draw, i + 1) if i + 1 < len(plan) else None
+                    zd = ctx.upload_pinned(slot, n)  # copy stream; this context's stream waits for it
                     keep.append(zd)  # stays allocated until the stream has consumed it
                     last = i + 1 == len(plan)
+                    tc = _time.perf_counter()
                     _capi.check(
-                        ctx.lib.edmp_denoise_guided_segment_dev(ctx.h, ptr(zd), batch_size, _capi.as_pd(s), _capi.as_pd(g), guided, t_hi, t_hi - k,
+                        ctx.lib.edmp_denoise_guided_segment_dev(ctx.h, ptr(zd), batch_size, _capi.as_pd(s), _capi.as_pd(g), guided, t_hi, t_hi - kk,
                                                                 1 if f else 0, 1 if zero_row0 else 0, ptr(out) if last else None),
                         "edmp_denoise_guided_segment_dev",
                     )
-                    t_hi -= k
+                    if trace is not None:
+                        ev = torch.cuda.Event(enable_timing=True)
+                        ev.record(ctx.stream)
+                        trace.append(("main", i, kk, ta - t_call, tb - t_call, tc - t_call, _time.perf_counter() - t_call, ev))
+                    t_hi -= kk
             if return_device:
                 ctx.sync()
                 return out
