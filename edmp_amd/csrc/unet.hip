@@ -608,7 +608,7 @@ static int level_kx(int variant) { return variant == 1 ? 16 : variant == 2 ? 32 
 // workgroups per CU (two waves per SIMD: one workgroup's GroupNorm / Mish epilogues, barriers and staging run under the other's
 // MFMAs).  EDMP_LEVEL_SB=<d1><d2><d3><d4> (digits 2 / 4 for variants 1..4) overrides at model-build time (A/B runs).
 static int level_sb(int variant) {
-    static const char kDefault[] = "4444";
+    static const char kDefault[] = "4222";  // same-box A/B (scripts/ab_models.py, round 3): -1.2 / -1.6 / -2.8 us per launch for variants 2 / 3 / 4, nothing for 1
     const char* e = getenv("EDMP_LEVEL_SB");
     const char* t = (e && strlen(e) == 4) ? e : kDefault;
     return t[variant - 1] == '2' ? 2 : 4;
