@@ -363,8 +363,8 @@ __global__ __launch_bounds__(256) void guide_kernel(GuideArgs<TIn> a, RobotConst
 }
 
 // deterministic sum of the per-row partials -> one f64 (the whole-batch ||g||^2, lib/guide.py:629)
-__global__ void reduce_rowsq_kernel(const double* __restrict__ rowsq, int B, double* __restrict__ out) {
-    __shared__ double sm[256];
+// (256 threads; the ONE summation order of sum(g^2): the stand-alone kernel and the update kernel's in-block sum share it)
+__device__ __forceinline__ double block_sum_rowsq(const double* __restrict__ rowsq, int B, double* sm) {
     double s = 0.0;
     for (int i = threadIdx.x; i < B; i += 256) s += rowsq[i];
     sm[threadIdx.x] = s;
@@ -373,7 +373,12 @@ __global__ void reduce_rowsq_kernel(const double* __restrict__ rowsq, int B, dou
         if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = sm[0];
+    return sm[0];
+}
+__global__ void reduce_rowsq_kernel(const double* __restrict__ rowsq, int B, double* __restrict__ out) {
+    __shared__ double sm[256];
+    const double tot = block_sum_rowsq(rowsq, B, sm);
+    if (threadIdx.x == 0) out[0] = tot;
 }
 
 // gradient1 = (1 - gn) * g + gn * (g / ||g||)   (lib/guide.py:627-629): f32 division, f64 mix; written as f64
@@ -487,7 +492,8 @@ int guide_prepare(edmp_ctx* ctx, int B, int L) {  // allocate the step scratch u
     if (g->graw != before) ctx->epoch++;
     return rc;
 }
-int guide_raw_gradient_from_X(edmp_ctx* ctx, const double* X_dev, int B, int N, int t) {
+// reduce = false: the caller's update kernel sums the per-row partials itself (device-resident loop without a hook)
+int guide_raw_gradient_from_X(edmp_ctx* ctx, const double* X_dev, int B, int N, int t, bool reduce) {
     Guide* g = ctx->guide;
     EDMP_REQUIRE(g && g->aabb && g->row_class, "scene/rows not set");
     EDMP_REQUIRE(B == g->B, "batch %d != rows set (%d)", B, g->B);
@@ -496,10 +502,11 @@ int guide_raw_gradient_from_X(edmp_ctx* ctx, const double* X_dev, int B, int N, 
     if (rc) return rc;
     rc = launch_guide<GM_GRAD, double>(ctx, X_dev, N, 1, B, N - 2, t, 1, 1, g->graw, g->rowsq);
     if (rc) return rc;
-    hipLaunchKernelGGL(reduce_rowsq_kernel, dim3(1), dim3(256), 0, ctx->stream, g->rowsq, B, g->sumsq);
+    if (reduce) hipLaunchKernelGGL(reduce_rowsq_kernel, dim3(1), dim3(256), 0, ctx->stream, g->rowsq, B, g->sumsq);
     EDMP_HIP_CHECK(hipGetLastError());
     return EDMP_OK;
 }
+const double* guide_rowsq(edmp_ctx* ctx) { return ctx->guide->rowsq; }
 int guide_set_startgoal(edmp_ctx* ctx, const double* start, const double* goal) {
     float s[7], gl[7];
     for (int i = 0; i < 7; ++i) {

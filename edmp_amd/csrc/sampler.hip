@@ -22,7 +22,8 @@ void set_error(const char* fmt, ...) {
 // unet.hip / guide.hip
 int unet_forward_impl(edmp_ctx* ctx, const float* x_dev, int B, int t, float* eps_dev);
 int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_done);
-int guide_raw_gradient_from_X(edmp_ctx* ctx, const double* X_dev, int B, int N, int t);
+int guide_raw_gradient_from_X(edmp_ctx* ctx, const double* X_dev, int B, int N, int t, bool reduce);
+const double* guide_rowsq(edmp_ctx* ctx);
 int guide_set_startgoal(edmp_ctx* ctx, const double* start, const double* goal);
 int guide_prepare(edmp_ctx* ctx, int B, int L);
 const float* guide_graw(edmp_ctx* ctx);
@@ -82,9 +83,14 @@ __global__ void psample_kernel(double* __restrict__ X, const float* __restrict__
 }
 
 // X[:, :, 1:-1] -= sched[:, t-1] * ((1-gn) g + gn g/||g||);  then X[:, :, 0] = start, X[:, :, -1] = goal
-__global__ void update_kernel(double* __restrict__ X, const float* __restrict__ graw, const double* __restrict__ sumsq,
-                              const double* __restrict__ grad_norm, const double* __restrict__ sched, int sched_T, int t, int B, int C, int N,
+// rowsq != nullptr: the whole-batch sum(g^2) is formed here from the per-row partials, by every block in the summation order
+// of reduce_rowsq_kernel (bit-identical) - one launch less per guided step of the device-resident loop
+__global__ __launch_bounds__(256) void update_kernel(double* __restrict__ X, const float* __restrict__ graw, const double* __restrict__ sumsq,
+                              const double* __restrict__ rowsq, const double* __restrict__ grad_norm, const double* __restrict__ sched, int sched_T, int t, int B, int C, int N,
                               const double* __restrict__ sg, int guided, double* __restrict__ grad_out, float* __restrict__ xin, int cond) {
+    __shared__ double sm[256];
+    double total = 0.0;
+    if (guided) total = rowsq ? block_sum_rowsq(rowsq, B, sm) : sumsq[0];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * C * N) return;
     const int l = i % N;
@@ -104,7 +110,7 @@ __global__ void update_kernel(double* __restrict__ X, const float* __restrict__ 
     } else if (guided) {
         const int L = N - 2;
         const size_t gi = ((size_t)b * C + c) * L + (l - 1);
-        const float nrm = (float)sqrt(sumsq[0]);
+        const float nrm = (float)sqrt(total);
         const float gv = graw[gi];
         const double gn = grad_norm[b];
         const double mixed = (1.0 - gn) * (double)gv + gn * (double)(gv / nrm);
@@ -352,7 +358,7 @@ static int step_a(edmp_ctx* ctx, double* X, const double* z, int B, int t, int z
     EDMP_HIP_CHECK(hipGetLastError());
     if (xpost_out) EDMP_HIP_CHECK(hipMemcpyAsync(xpost_out, X, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (g) {
-        rc = guide_raw_gradient_from_X(ctx, X, B, N, t);
+        rc = guide_raw_gradient_from_X(ctx, X, B, N, t, /*reduce=*/!(fused && !s->ar_fn));
         if (rc) return rc;
     }
     return EDMP_OK;
@@ -365,7 +371,7 @@ static int step_b(edmp_ctx* ctx, double* X, int B, int t, int guided, double* gr
     hipStream_t st = ctx->stream;
     if (guided && guided_step(t)) {
         const int n = B * C * N;
-        hipLaunchKernelGGL(update_kernel, dim3((n + 255) / 256), dim3(256), 0, st, X, guide_graw(ctx), guide_sumsq(ctx), guide_grad_norm(ctx),
+        hipLaunchKernelGGL(update_kernel, dim3((n + 255) / 256), dim3(256), 0, st, X, guide_graw(ctx), guide_sumsq(ctx), (fused && !s->ar_fn) ? guide_rowsq(ctx) : nullptr, guide_grad_norm(ctx),
                            guide_sched(ctx), guide_rows_T(ctx), t, B, C, N, s->sg, 1, grad_out, fused ? u->x_in : nullptr, s->condition);
     } else if (!fused && s->condition) {
         hipLaunchKernelGGL(condition_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, X, B, C, N, s->sg);

@@ -603,6 +603,17 @@ def test_infer_serial_driver_c1():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = infer_serial.run(os.path.join(root, "configs", "cfg_c1_plumbing.yaml"), verbose=False)
     assert len(res) == 1 and res[0]["trajectory"].shape == (7, 50) and np.isfinite(res[0]["trajectory"]).all()
+    assert res[0]["rows"] == 4 and 0 <= res[0]["rows_ok"] <= 4 and res[0]["success_proxy"] in (0, 1)
+    # a dataset that hands cuboids AND cylinders (fetch_data contract of datasets/load_test_dataset.py:76-189): the driver marks
+    # the cylinder rows for the success check (infer_serial.py:159-163 spawns them as true cylinders); flags = the checker's
+    from edmp_amd import scenes
+    from oracle import success_oracle as SO
+
+    ds = scenes.SyntheticDataset(scene_types=("stress",), n_obstacles=6, n_cylinders=2)
+    res = infer_serial.run(os.path.join(root, "configs", "cfg_c1_plumbing.yaml"), dataset=ds, verbose=False)
+    oc = ds.fetch_data(0, "stress")[0]
+    ref = SO.success_rows(res[0]["trajectory"][None], oc, kinds=np.array([0, 0, 0, 0, 1, 1]))
+    assert res[0]["success_proxy"] == int(ref["ok"][0]) and res[0]["first_collision_waypoint"] == int(ref["first"][0])
 
 
 def test_device_noise_mode(tiny_net):
