@@ -106,6 +106,20 @@ int main(int argc, char** argv) {
     int32_t b32 = best;
     fwrite(&b32, 4, 1, o);
     fwrite(vol, 4, B, o);
+    /* plan success of every row (edmp_success_rows_dev): the last obstacle marked as a true cylinder; flags + counts appended */
+    {
+        int32_t* kinds = calloc((size_t)no, 4);
+        kinds[no - 1] = 1;
+        CHECK(edmp_scene_set_shapes(ctx, kinds, no));
+        int32_t *d_flags = NULL, counts[4] = {0, 0, 0, 0};
+        HIPCHECK(hipMalloc((void**)&d_flags, (size_t)3 * B * 4));
+        CHECK(edmp_success_rows_dev(ctx, d_X, B, 50, 4, NULL, d_flags, d_flags + B, d_flags + 2 * B, counts));
+        int32_t* flags = malloc((size_t)3 * B * 4);
+        HIPCHECK(hipMemcpy(flags, d_flags, (size_t)3 * B * 4, hipMemcpyDeviceToHost));
+        fwrite(flags, 4, (size_t)3 * B, o);
+        fwrite(counts, 4, 4, o);
+        if (edmp_scene_set_shapes(ctx, kinds, no + 1) == 0) return 8; /* wrong length is refused */
+    }
     fclose(o);
     /* error behaviour: bad arguments are reported, not crashed on */
     if (edmp_unet_forward_dev(ctx, NULL, 1, 1, NULL) == 0) return 6;

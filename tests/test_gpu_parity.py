@@ -694,8 +694,19 @@ def test_plain_c_host_through_the_c_abi(golden, tmp_path):
     n = B * 7 * 50
     Xc = np.frombuffer(raw[: n * 8], dtype=np.float64).reshape(B, 7, 50)
     best = struct.unpack("<i", raw[n * 8 : n * 8 + 4])[0]
-    vols = np.frombuffer(raw[n * 8 + 4 :], dtype=np.float32)
+    vols = np.frombuffer(raw[n * 8 + 4 : n * 8 + 4 + 4 * B], dtype=np.float32)
+    tail = np.frombuffer(raw[n * 8 + 4 + 4 * B :], dtype=np.int32)
+    flags, counts = tail[: 3 * B].reshape(3, B), tail[3 * B :]
     assert rmse(Xc, g["x_out_253"]) <= 1e-4, rmse(Xc, g["x_out_253"])
+    # the success check through the plain-C host (last obstacle a true cylinder; dh_f64 = NULL: the widened f32 table) equals
+    # the Python mirror's flags on the same state
+    from oracle import success_oracle as SO
+
+    kinds = np.zeros(g["scene"].shape[0], dtype=np.int32)
+    kinds[-1] = 1
+    ref = SO.success_rows(Xc, g["scene"], kinds=kinds)
+    assert np.array_equal(flags[0].astype(bool), ref["ok"]) and np.array_equal(flags[1], ref["first"]) and np.array_equal(flags[2].astype(bool), ref["within"])
+    assert counts.tolist() == [int(ref["ok"].sum()), int(ref["within"].sum()), int((ref["first"] < 0).sum()), B]
     # identical to the Python mirror (same library underneath)
     net = TemporalUNet(None, 7, 32, DEV, dims=TINY_DIMS, state_dict=sd, max_batch=B)
     guide = IntersectionVolumeGuide(g["scene"], DEV, cfgs, B)
