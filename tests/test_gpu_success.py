@@ -168,6 +168,25 @@ def test_success_inside_the_sampler_flow_and_gather():
     assert best["rows_ok"] == int(ref["ok"].sum()) and best["rows"] == B and best["success"] == bool(ref["ok"][idx])
 
 
+@pytest.mark.parametrize("B,N,no,S", [(1, 50, 1, 4), (3, 2, 64, 1), (5, 64, 7, 64), (257, 9, 33, 3)])
+def test_success_edge_sizes(B, N, no, S):
+    """one row / two waypoints / the maximum of 64 obstacles / 64 waypoints with the maximum of 64 sub-steps (4033 configurations
+    per row: the thread loop wraps 16 times) / a batch that is no multiple of anything."""
+    from edmp_amd import franka, scenes
+    from oracle import success_oracle as SO
+
+    rs = np.random.RandomState(B * 1000 + N)
+    lo, hi = franka.joint_limits()
+    scene = scenes.random_scene(100 + no, no)
+    scene[:, 7:10] *= 0.35
+    kinds = (rs.rand(no) < 0.4).astype(np.int32)
+    scene[kinds == 1, 8] = scene[kinds == 1, 7]
+    X = _rows(rs, B, N, lo, hi, spread=0.3)
+    res = _guide(scene, B, kinds).success_rows(X, substeps=S)
+    _compare(res, SO.success_rows(X, scene, substeps=S, kinds=kinds), (B, N, no, S))
+    assert res["rows"] == B
+
+
 def test_success_error_behaviour():
     import ctypes as C
 
@@ -187,3 +206,7 @@ def test_success_error_behaviour():
     assert b"edmp_success_rows_dev" in ctx.lib.edmp_last_error()
     bad = (C.c_int32 * 3)(0, 5, 0)
     assert ctx.lib.edmp_scene_set_shapes(ctx.h, bad, 3) == -1
+    with pytest.raises(_capi.EdmpError):
+        g.success_rows(np.zeros((2, 7, 50)), substeps=65)
+    with pytest.raises(_capi.EdmpError):
+        g.success_rows(np.zeros((2, 7, 1)))
