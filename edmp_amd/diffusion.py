@@ -241,8 +241,8 @@ class Diffusion:
 
             t_hi, keep = self.T, []
             pool = ctx.draw_pool()  # ONE long-lived draw thread per context: its OpenMP team stays alive (and warm) between scenes
-            if True:
-                pending = pool.submit(draw, 0) if plan else None
+            pending = pool.submit(draw, 0) if plan else None
+            try:
                 for i, (kk, f) in enumerate(plan):
                     ta = _time.perf_counter()
                     slot, n = pending.result()
@@ -262,6 +262,19 @@ class Diffusion:
                         ev.record(ctx.stream)
                         trace.append(("main", i, kk, ta - t_call, tb - t_call, tc - t_call, _time.perf_counter() - t_call, ev))
                     t_hi -= kk
+            except BaseException:
+                # leave nothing in flight that still reads the staging ring or the chunk tensors: the draw thread finishes its
+                # current chunk, the stream drains, then the error propagates
+                if pending is not None:
+                    try:
+                        pending.result()
+                    except Exception:
+                        pass
+                try:
+                    ctx.sync()
+                except Exception:
+                    pass
+                raise
             if return_device:
                 ctx.sync()
                 return out
