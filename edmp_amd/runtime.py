@@ -171,6 +171,11 @@ def new_slot_key() -> int:
 
 
 def get_context(device) -> Context:
+    """the per-GPU context of `device` ("cuda:<i>").  A `Context` instance passes through: objects built on an explicitly
+    created second context (`Context(i)`) live on their own stream with their own resident model / guides - two scenes in
+    flight on one GPU (scripts/two_scenes.py)."""
+    if isinstance(device, Context):
+        return device
     idx = _device_index(device)
     if idx not in _contexts:
         _contexts[idx] = Context(idx)
