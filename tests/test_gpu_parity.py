@@ -616,6 +616,28 @@ def test_infer_serial_driver_c1():
     assert res[0]["success_proxy"] == int(ref["ok"][0]) and res[0]["first_collision_waypoint"] == int(ref["first"][0])
 
 
+def test_infer_serial_two_scenes_in_flight():
+    """the driver with two scenes planned concurrently on one GPU (two contexts, two host threads) returns, scene by scene, what
+    the serial loop returns under the same np.random seed - bit for bit (noise drawn per scene, in scene order, on the caller's thread)."""
+    import os
+
+    import infer_serial
+    from edmp_amd import scenes
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = os.path.join(root, "configs", "cfg_c1_plumbing.yaml")
+    out = []
+    for k in (1, 2):
+        np.random.seed(77)
+        ds = scenes.SyntheticDataset(scene_types=("stress",), num_scenes_per_type=3, n_obstacles=6, n_cylinders=1)
+        out.append(infer_serial.run(cfg, dataset=ds, verbose=False, scenes_in_flight=k))
+    assert len(out[0]) == len(out[1]) == 3
+    for a, b in zip(*out):
+        assert (a["scene_num"], a["best_row"], a["success_proxy"], a["rows_ok"]) == (b["scene_num"], b["best_row"], b["success_proxy"], b["rows_ok"])
+        assert np.array_equal(a["trajectory"], b["trajectory"])
+    assert not np.array_equal(out[0][0]["trajectory"], out[0][1]["trajectory"])  # different scenes, different noise
+
+
 def test_device_noise_mode(tiny_net):
     """noise="device" (Philox on the GPU, explicitly non-parity): statistics of the stream, determinism, seed / step
     independence, and the loop driven by it equals the loop driven by the materialised stream."""
