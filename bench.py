@@ -239,11 +239,16 @@ def main():
         noise2 = ctx2.to_dev(np.random.RandomState(4321).standard_normal((T + 1, B, C, N)), torch.float64)
         ctx2.sync()
 
+        chain_errors = []
+
         def chain(d, n_, g_, z_, k):
-            for _ in range(k):
-                X = d.denoise_guided(n_, g_, N, C, cfgs["guidance_schedule"], batch_size=B, start=start, goal=goal, noise=z_, return_device=True)
-                g_.row_swept_volumes(start, goal, X)
-                g_.success_rows(X)
+            try:
+                for _ in range(k):
+                    X = d.denoise_guided(n_, g_, N, C, cfgs["guidance_schedule"], batch_size=B, start=start, goal=goal, noise=z_, return_device=True)
+                    g_.row_swept_volumes(start, goal, X)
+                    g_.success_rows(X)
+            except BaseException as exc:  # a thread must not fail silently: the pair time would be meaningless
+                chain_errors.append(exc)
 
         chain(dif2, net2, guide2, noise2, 1)
         torch.cuda.synchronize()
@@ -256,6 +261,8 @@ def main():
             th.join()
         torch.cuda.synchronize()
         t_pair = (time.perf_counter() - t1) / k2
+        if chain_errors:
+            raise chain_errors[0]
         out["two_scenes_in_flight"] = {"traj_steps_per_s": 2 * B * T / t_pair, "ms_per_pair_of_scenes": 1e3 * t_pair, "vs_value": (2 * B * T / t_pair) / value,
                                        "note": "two independent 1024-row scenes on two contexts (streams) of this GPU, one host thread each; results bit-identical to the "
                                                "one-at-a-time runs; informative, not the named config (one batch of 1024)"}
