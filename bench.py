@@ -75,13 +75,30 @@ def main():
     ap.add_argument("--no-two-scenes", action="store_true", help="skip the informative two-scenes-in-flight measurement")
     args = ap.parse_args()
 
+    backend = os.environ.get("EDMP_DIST_BACKEND", "nccl")  # "gloo" lets N ranks share one GPU (single-GPU test boxes)
+    ngpu = torch.cuda.device_count()
+    if args.gpus < 1:
+        raise SystemExit(f"--gpus {args.gpus}: need at least one rank")
+    if args.gpus > 1 and backend == "nccl" and ngpu < args.gpus:
+        # RCCL refuses two ranks on one device; a run that silently used fewer GPUs would print a mislabelled line
+        raise SystemExit(f"--gpus {args.gpus} but only {ngpu} GPU(s) visible (EDMP_DIST_BACKEND=gloo lets ranks share a GPU: test boxes only)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N` (the reference's launch model is one process per device,
+        # benchmark/cfgs/cfg2.yaml:2,14): re-exec under the launcher the contract names instead of falling through to one rank
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__), *sys.argv[1:]]
+        print(f"[bench] --gpus {args.gpus} without a launcher: re-exec as {' '.join(cmd[1:9])} ...", file=sys.stderr, flush=True)
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    ngpu = torch.cuda.device_count()
-    backend = os.environ.get("EDMP_DIST_BACKEND", "nccl")  # "gloo" lets N ranks share one GPU (single-GPU test boxes)
     dev_index = local_rank if backend == "nccl" else local_rank % max(ngpu, 1)
     torch.cuda.set_device(dev_index)
     dev = f"cuda:{dev_index}"
@@ -130,14 +147,18 @@ def main():
     # logical-batch mode issues the collective even in a world of one, so that N = 1 measures the hook + RCCL launch cost
     ar = functools.partial(ED.allreduce_sum_, always=(world > 1 or (dist.is_available() and dist.is_initialized()))) if logical else None
 
+    last = {}
+
     def one_call():
         X = dif.denoise_guided(net, guide, N, C, cfgs["guidance_schedule"], batch_size=B, start=start, goal=goal, noise=noise, return_device=True,
                                allreduce=ar, zero_row0=(rank == 0 or not logical))
         vols, idx = guide.row_swept_volumes(start, goal, X)  # synchronises (argmin comes back to the host)
         # plan success of EVERY row (exact link-box vs obstacle check, csrc/success.hip): the second half of the metric
         sr = guide.success_rows(X)
+        last["X"] = X
         traj = X[idx].cpu().numpy()
-        res = ED.gather_best(float(vols[idx]), idx, traj, bool(sr["ok"][idx]), device=dev, rows_ok=sr["rows_ok"], rows=sr["rows"])
+        res = ED.gather_best(float(vols[idx]), idx, traj, bool(sr["ok"][idx]), device=dev, rows_ok=sr["rows_ok"], rows=sr["rows"],
+                             collision_free=bool(sr["collision_free"][idx]), rows_collision_free=sr["rows_collision_free"])
         res["aabb_volume_zero"] = ED.geometric_success(float(vols[idx]), traj)  # the guide's own (conservative) criterion, rank-local
         return res
 
@@ -155,10 +176,17 @@ def main():
         best = one_call()
     barrier()
     dt = time.perf_counter() - t0
+    n_ranks_seen = 1
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # the world size the collective library actually ran with: every rank contributes 1 to a SUM
+        ones = torch.ones(1, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        n_ranks_seen = int(round(float(ones.item())))
+        if n_ranks_seen != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group summed {n_ranks_seen} ranks")
     value = world * B * T * args.steps / dt
 
     out = None
@@ -169,6 +197,8 @@ def main():
             "value": value,
             "unit": "traj-steps/s",
             "n_gpus": world,
+            "n_ranks_seen": n_ranks_seen,  # summed over the process group (RCCL / gloo) inside the run: equals n_gpus or the run aborts
+            "dist_backend": (backend if world > 1 else None),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
@@ -184,11 +214,15 @@ def main():
                                 if logical else (f"row-sharded replicas x{world}, end-of-sampling RCCL gather" if world > 1 else "single GPU")),
             },
             "best": {"rank": best["rank"], "row": best["index"], "swept_volume": best["volume"], "aabb_volume_zero_and_within_limits": best["aabb_volume_zero"]},
-            "success_proxy": {"rows_ok": best["rows_ok"], "rows": best["rows"], "rate": best["rows_ok"] / max(best["rows"], 1), "best_row_ok": best["success"],
-                              "note": "plan success-rate half of the metric, computed INSIDE the timed call for every row of the batch (summed over ranks): all waypoints "
-                                      "within the joint limits and no link box meeting an obstacle (exact oriented-box / cylinder test, 4 interpolated configurations per "
-                                      "segment) - a geometric stand-in for the reference's pybullet check (lib/environment.py:632-680), which is unavailable offline; "
-                                      "random-init denoiser (no trained weights offline): the rate says nothing about planning quality, it is reported, never gated"},
+            "success_proxy": {"rows_collision_free": best["rows_collision_free"], "rows": best["rows"],
+                              "collision_free_rate": best["rows_collision_free"] / max(best["rows"], 1), "best_row_collision_free": best["collision_free"],
+                              "rows_ok": best["rows_ok"], "rate": best["rows_ok"] / max(best["rows"], 1), "best_row_ok": best["success"],
+                              "note": "plan success-rate half of the metric, computed INSIDE the timed call for every row of the batch (summed over ranks).  "
+                                      "collision_free_rate / best_row_collision_free = the REFERENCE's criterion: no link box meets an obstacle (exact oriented-box / "
+                                      "cylinder test, 4 interpolated configurations per segment); leaving the joint limits only prints there (lib/environment.py:659-661, "
+                                      "672).  rate / best_row_ok = the stricter flag that also requires every waypoint inside the limits.  A geometric stand-in for the "
+                                      "reference's pybullet check (lib/environment.py:632-680), which is unavailable offline; random-init denoiser (no trained weights "
+                                      "offline): the rates say nothing about planning quality, they are reported, never gated"},
             # one logical batch: host time of the per-guided-step hook (Python ctypes callback that enqueues the RCCL
             # all-reduce of sum(g^2) on the context's stream), rank 0, last call
             "allreduce_hook": (None if not logical else {"calls_per_denoise": dif.hook_stats["calls"], "avg_us": 1e6 * dif.hook_stats["total_s"] / max(dif.hook_stats["calls"], 1),
@@ -196,6 +230,43 @@ def main():
             "unet_flops_per_traj_step": {"nominal": nominal, "direct_form_after_tap_skipping": net.flops_direct_form(), "issued_mfma": executed, "survey": SURVEY_FLOPS_PER_TRAJ_STEP,
                                          "note": "issued < direct form: the L=2 / L=4 Conv1dBlocks run in Karatsuba form (3 of 4 resp. 9 of 14 matrix products)"},
         }
+
+    # ---- cost of the success kernel: on the batch just produced (random-init rows collide early and leave the obstacle loop at the
+    # first hit: the EASY case) and on a collision-free in-limit batch against the scene moved 10 m away (every configuration x link
+    # box x obstacle tested: the WORST case, what trained weights should produce) ------------------------------------------------
+    if world == 1 and rank == 0:
+        from edmp_amd import franka
+
+        def timed_check(g_, X_):
+            g_.success_rows(X_, return_device=True)
+            best_ms = 1e9
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(ctx.stream)
+                r_ = g_.success_rows(X_, return_device=True)
+                e1.record(ctx.stream)
+                e1.synchronize()
+                best_ms = min(best_ms, e0.elapsed_time(e1))
+            return best_ms, r_
+
+        ms_this, _ = timed_check(guide, last["X"])
+        far = scene.copy()
+        far[:, 0] += 10.0
+        kinds = np.zeros(far.shape[0], dtype=np.int32)
+        kinds[:: 5] = 1  # every fifth obstacle a true cylinder of radius dims[0] (dims = (r, r, h), datasets/load_test_dataset.py:136-139)
+        far[kinds == 1, 8] = far[kinds == 1, 7]
+        lo_q, hi_q = franka.joint_limits()
+        rs_ = np.random.RandomState(5)
+        qa, qb = rs_.uniform(lo_q + 0.05, hi_q - 0.05, (B, C)), rs_.uniform(lo_q + 0.05, hi_q - 0.05, (B, C))
+        tt_ = np.linspace(0.0, 1.0, N)
+        Xfree = ctx.to_dev(qa[:, :, None] * (1 - tt_) + qb[:, :, None] * tt_, torch.float64)
+        gfar = IntersectionVolumeGuide(far, dev, cfgs, B, obstacle_kinds=kinds)
+        ms_free, r_free = timed_check(gfar, Xfree)
+        guide.success_rows(last["X"])  # re-bind the bench scene
+        out["success_proxy"]["check_ms"] = {"this_batch": ms_this, "collision_free_batch_worst_case": ms_free, "collision_free_rows_of_that_batch": r_free["rows_collision_free"],
+                                            "share_of_step_worst_case": ms_free / (1e3 * dt / args.steps),
+                                            "note": "edmp_success_rows_dev incl. the flag count and its 16-byte read-back, HIP events on the context's stream, best of 3"}
+        del gfar, Xfree
 
     # ---- informative: whole-scene wall time when the noise is NOT pre-resident (never `value`) -------------------------
     if world == 1 and rank == 0 and not logical:

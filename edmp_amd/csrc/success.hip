@@ -7,7 +7,11 @@
 // 165-168).  pybullet is a third-party dependency absent offline ("parity unpinned"), so the criterion is geometric and
 // exact on the primitives the guide uses for the robot: the 9 link boxes (lib/guide.py:243-342) in float64 modified-DH
 // poses against every obstacle, at every waypoint and at `substeps` joint-space interpolated configurations per segment,
-// plus the joint-limit test the reference prints (:659-661).  Checker: oracle/success_oracle.py (same arithmetic, NumPy).
+// plus the joint-limit test.  The reference only PRINTS "Joint Limits Exceeded" (:659-661); its success is num_collisions == 0
+// alone (:672).  Per row the kernel therefore reports three things: first (first colliding waypoint, -1 = collision-free = the
+// reference's success), within (all waypoints inside the limits) and ok = within && collision-free, the STRICTER flag; callers
+// tally `first < 0` where the reference's number is meant (infer_serial.py, bench.py success_proxy.collision_free_rate) and
+// report `ok` beside it.  Checker: oracle/success_oracle.py (same arithmetic, NumPy).
 //
 // Design: one workgroup per trajectory row, thread = configuration (waypoint i, sub-step s): 197 configurations at N = 50,
 // S = 4.  Each thread walks the DH chain in f64 and tests the link boxes riding each frame against the obstacles staged in

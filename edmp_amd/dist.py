@@ -38,20 +38,26 @@ def _comm_device(device=None):
     return torch.device("cpu")
 
 
-def gather_best(local_volume: float, local_index: int, local_traj, success: bool, device=None, group=None, always=False, rows_ok: int = 0, rows: int = 0):
+def gather_best(local_volume: float, local_index: int, local_traj, success: bool, device=None, group=None, always=False, rows_ok: int = 0, rows: int = 0,
+                collision_free=None, rows_collision_free: int = 0):
     """End-of-sampling exchange.  Returns dict(volume, rank, index, traj (7,50) f64 ndarray, success, n_success, rows_ok,
     rows).  ``success`` is the flag of the winning row; ``rows_ok`` / ``rows`` are this rank's batch success counts
     (IntersectionVolumeGuide.success_rows) and come back SUMMED over the ranks - the job-wide plan success rate.
+    ``collision_free`` / ``rows_collision_free``: the same pair under the REFERENCE's criterion - no contact, joint limits only
+    printed (lib/environment.py:659-661, 672) - where ``success`` / ``rows_ok`` also require every waypoint inside the limits;
+    ``collision_free=None`` (callers that predate the split) reports the strict flag for both.
     Ties resolve to the lowest rank (= lowest global row index, like torch.argmin over the unsharded batch).
     ``always``: run the collectives even in a world of one (exercises the RCCL path on a single-GPU box)."""
     traj = np.asarray(local_traj, dtype=np.float64)
+    cfree = bool(success) if collision_free is None else bool(collision_free)
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not always):
         return dict(volume=float(local_volume), rank=0, index=int(local_index), traj=traj.copy(), success=bool(success), n_success=int(bool(success)),
-                    rows_ok=int(rows_ok), rows=int(rows))
+                    rows_ok=int(rows_ok), rows=int(rows), collision_free=cfree, rows_collision_free=int(rows_collision_free))
     dev = _comm_device(device)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    mine = torch.tensor([float(local_volume), float(local_index), 1.0 if success else 0.0, float(rows_ok), float(rows)], dtype=torch.float64, device=dev)
+    mine = torch.tensor([float(local_volume), float(local_index), 1.0 if success else 0.0, float(rows_ok), float(rows), 1.0 if cfree else 0.0, float(rows_collision_free)],
+                        dtype=torch.float64, device=dev)
     allv = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(allv, mine, group=group)
     table = torch.stack(allv).cpu().numpy()
@@ -60,7 +66,8 @@ def gather_best(local_volume: float, local_index: int, local_traj, success: bool
     t = torch.from_numpy(traj.copy()).to(dev) if rank == owner else torch.empty(traj.shape, dtype=torch.float64, device=dev)
     dist.broadcast(t, src=owner if group is None else dist.get_global_rank(group, owner), group=group)
     return dict(volume=float(vols[owner]), rank=owner, index=int(table[owner, 1]), traj=t.cpu().numpy(), success=bool(table[owner, 2] > 0),
-                n_success=int((table[:, 2] > 0).sum()), rows_ok=int(table[:, 3].sum()), rows=int(table[:, 4].sum()))
+                n_success=int((table[:, 2] > 0).sum()), rows_ok=int(table[:, 3].sum()), rows=int(table[:, 4].sum()), collision_free=bool(table[owner, 5] > 0),
+                rows_collision_free=int(table[:, 6].sum()))
 
 
 def allreduce_sum_(t: torch.Tensor, group=None, always=False):

@@ -24,13 +24,15 @@ def _dh(a, d, alpha, q):
 
 
 def geometric_success(trajectory, guide, substeps: int = 4) -> dict:
-    """ONE trajectory (7, N) against the scene of `guide` (an IntersectionVolumeGuide): dict(success,
-    first_collision_waypoint, within_limits).  Runs on the GPU (one-row batch of guide.success_rows)."""
+    """ONE trajectory (7, N) against the scene of `guide` (an IntersectionVolumeGuide): dict(success, collision_free,
+    first_collision_waypoint, within_limits).  `collision_free` is the reference's success flag (lib/environment.py:672: contact
+    only; leaving the limits merely prints, :659-661), `success` additionally requires `within_limits`.  Runs on the GPU (one-row
+    batch of guide.success_rows)."""
     tr = np.asarray(trajectory, dtype=np.float64)
     if tr.ndim != 2 or tr.shape[0] != 7:
         raise ValueError(f"trajectory must be (7, N), got {tr.shape}")
     r = guide.success_rows(tr[None], substeps=substeps)
-    return dict(success=bool(r["ok"][0]), first_collision_waypoint=int(r["first"][0]), within_limits=bool(r["within"][0]))
+    return dict(success=bool(r["ok"][0]), collision_free=bool(r["collision_free"][0]), first_collision_waypoint=int(r["first"][0]), within_limits=bool(r["within"][0]))
 
 
 def success_rate(trajectories, guide, substeps: int = 4) -> dict:
@@ -38,6 +40,7 @@ def success_rate(trajectories, guide, substeps: int = 4) -> dict:
     reference's running tally `t_success / i` (infer_serial.py:99)."""
     r = guide.success_rows(trajectories, substeps=substeps)
     r["rate"] = r["rows_ok"] / max(r["rows"], 1)
+    r["collision_free_rate"] = r["rows_collision_free"] / max(r["rows"], 1)  # the reference's criterion (lib/environment.py:672)
     return r
 
 

@@ -203,8 +203,11 @@ class IntersectionVolumeGuide:
     def success_rows(self, trajectories, substeps: int = 4, return_device: bool = False):
         """Geometric success of EVERY row (edmp_success_rows_dev; stands for RobotEnvironment.benchmark_trajectory,
         lib/environment.py:632-680, and the tally of infer_serial.py:94-99,165-168): trajectories (B,7,N) ndarray or device
-        tensor -> dict(ok (B,) bool, first (B,) int32 first colliding waypoint or -1, within (B,) bool, rows_ok, rows_within,
-        rows_collision_free, rows).  With return_device the three per-row arrays stay int32 device tensors."""
+        tensor -> dict(ok (B,) bool, first (B,) int32 first colliding waypoint or -1, within (B,) bool, collision_free (B,) bool,
+        rows_ok, rows_within, rows_collision_free, rows).  ``collision_free`` (= first < 0) is the REFERENCE's success flag: its
+        benchmark_trajectory fails a plan on contact only and merely prints when the joint limits are left
+        (lib/environment.py:659-661, 672); ``ok`` = collision_free AND within, the stricter flag.  With return_device the per-row
+        arrays stay device tensors (ok / first / within int32, collision_free bool)."""
         self._bind()
         ctx = self.ctx
         if isinstance(trajectories, torch.Tensor) and trajectories.is_cuda:
@@ -221,10 +224,12 @@ class IntersectionVolumeGuide:
                                                   C.c_void_p(flags[1].data_ptr()), C.c_void_p(flags[2].data_ptr()), counts), "edmp_success_rows_dev")
         out = dict(rows_ok=int(counts[0]), rows_within=int(counts[1]), rows_collision_free=int(counts[2]), rows=int(counts[3]))
         if return_device:
-            out.update(ok=flags[0], first=flags[1], within=flags[2])
+            with torch.cuda.stream(ctx.stream):
+                cf = flags[1] < 0
+            out.update(ok=flags[0], first=flags[1], within=flags[2], collision_free=cf)
         else:
             f = ctx.to_host(flags)
-            out.update(ok=f[0].astype(bool), first=f[1].copy(), within=f[2].astype(bool))
+            out.update(ok=f[0].astype(bool), first=f[1].copy(), within=f[2].astype(bool), collision_free=f[1] < 0)
         return out
 
     def choose_best_trajectory(self, start, goal, trajectories):

@@ -113,3 +113,44 @@ def save_problem_file(path: str, obstacle_config, start, goals) -> None:
         cub.append({"center": o[:3].tolist(), "quaternion_wxyz": [w, x, y, z], "dims": o[7:10].tolist()})
     with open(path, "w") as f:
         json.dump({"cuboids": cub, "cylinders": [], "start": np.asarray(start, float).tolist(), "goals": np.atleast_2d(goals).tolist()}, f)
+
+
+class ProblemSetDataset:
+    """``TestDataset`` (datasets/load_test_dataset.py:15-189) over a problem-set JSON written by
+    ``scripts/mpinets_pkl_to_json.py`` from an MPiNets pickle: same ``data_nums`` / ``fetch_data`` contract, same conversions
+    (w-first -> w-last roll :126,:133; cuboids before cylinders :141-149; a cylinder row of ``obstacle_config`` is the box
+    (r, r, h) :136-139; ``cylinder_config`` rows are [xyz, quat xyzw, radius, height] :131-134).  ``data_nums['merged_cubby']``
+    is the length of the CUBBY list, like the reference's (:61).
+
+    IK goals (robofin's ikfast on the problem's target pose, :170-187) are an explicit input: the problem's own ``goals`` list if
+    the file carries one, else ``ik(target_xyz, target_quaternion_wxyz) -> (n, 7)`` if a callable is given; neither -> ValueError."""
+
+    def __init__(self, path, ik=None):
+        import json
+
+        with open(path) as f:
+            doc = json.load(f)
+        if "scene_types" not in doc:
+            raise ValueError(f"{path}: not a problem-set file (no 'scene_types'); a single problem loads with scenes.load_problem_file")
+        self.problems = doc["scene_types"]
+        self.ik = ik
+        self.data_nums = {st: len(pr) for st, pr in self.problems.items()}
+        if "merged_cubby" in self.data_nums and "cubby" in self.data_nums:
+            self.data_nums["merged_cubby"] = len(self.problems["cubby"])  # datasets/load_test_dataset.py:61
+
+    def fetch_data(self, scene_num, scene_type="tabletop"):
+        if scene_type not in self.problems:
+            raise ModuleNotFoundError(f"no scene type {scene_type!r} in this problem set ({sorted(self.problems)})")
+        pr = self.problems[scene_type][scene_num]
+        if "goals" in pr and len(pr["goals"]):
+            goals = np.atleast_2d(np.asarray(pr["goals"], dtype=np.float64))
+        elif self.ik is not None:
+            goals = np.atleast_2d(np.asarray(self.ik(np.asarray(pr["target"]["xyz"], float), np.asarray(pr["target"]["quaternion_wxyz"], float)), dtype=np.float64))
+        else:
+            raise ValueError(f"{scene_type}[{scene_num}] carries no IK goals and no ik callable was given (robofin is not part of this package: "
+                             "compute FrankaRobot.ik of the target elsewhere and pass --ik-goals to the converter, or ik= here)")
+        oc, start, _ = problem_to_arrays({**pr, "goals": goals})
+        nb, nc = len(pr.get("cuboids", [])), len(pr.get("cylinders", []))
+        cub = oc[:nb].copy() if nb else []
+        cyl = np.concatenate([oc[nb:, :7], oc[nb:, 7:8], oc[nb:, 9:10]], axis=1) if nc else []
+        return oc, cub, cyl, nb, nc, start, goals

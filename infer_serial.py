@@ -70,24 +70,27 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=
         t_plan = time.time() - t0
         # success: pybullet execution (lib/environment.py:632-680) is unavailable -> exact link-box vs cuboid / cylinder
         # check along the interpolated trajectory, for EVERY row of the batch in one kernel (csrc/success.hip); the
-        # scene's success is the chosen row's flag (infer_serial.py:165-168), the batch rate is reported next to it,
-        # as is the guide's own (conservative, AABB) criterion
+        # scene's success is the chosen row's flag (infer_serial.py:165-168) under the reference's rule - no contact;
+        # leaving the joint limits only prints there (lib/environment.py:659-661, 672) -, the stricter flag (also inside the
+        # limits) and the batch rates are reported next to it, as is the guide's own (conservative, AABB) criterion
         chk = guide.success_rows(trajectories)
-        return dict(**meta, best_row=int(idx), swept_volume=float(vols[idx]), success_proxy=int(chk["ok"][idx]), rows_ok=chk["rows_ok"], rows=chk["rows"],
+        return dict(**meta, best_row=int(idx), swept_volume=float(vols[idx]), success_proxy=int(chk["collision_free"][idx]), success_strict=int(chk["ok"][idx]),
+                    rows_collision_free=chk["rows_collision_free"], rows_ok=chk["rows_ok"], rows=chk["rows"],
                     aabb_volume_zero=bool(ED.geometric_success(float(vols[idx]), trajectory)), first_collision_waypoint=int(chk["first"][idx]),
                     path_length=EV.path_lengths(trajectory), sparc=EV.smoothness(trajectory), planning_time_s=t_plan, trajectory=trajectory)
 
-    t_success, i, results, pending = 0, 0, [], []
+    t_success, t_strict, i, results, pending = 0, 0, 0, [], []
 
     def collect(fut):
-        nonlocal t_success
+        nonlocal t_success, t_strict
         r = fut.result() if hasattr(fut, "result") else fut
         results.append(r)
-        t_success += r["success_proxy"]
+        t_success += r["success_proxy"]  # the reference's tally: collision-free (infer_serial.py:165-168 on lib/environment.py:672)
+        t_strict += r["success_strict"]
         if verbose:
             print(f"Scene {len(results)} ({r['scene_type']}/{r['scene_num']}): planning {r['planning_time_s']:.2f} s, best row {r['best_row']}, swept volume "
-                  f"{r['swept_volume']:.4g}, geometric success (proxy) {r['success_proxy']} ({r['rows_ok']}/{r['rows']} rows of the batch)   "
-                  f"running {t_success}/{len(results)}")
+                  f"{r['swept_volume']:.4g}, geometric success (proxy, collision-free) {r['success_proxy']} ({r['rows_collision_free']}/{r['rows']} rows of the batch); "
+                  f"also within the joint limits {r['success_strict']} ({r['rows_ok']}/{r['rows']})   running {t_success}/{len(results)} (strict {t_strict}/{len(results)})")
 
     with ThreadPoolExecutor(max_workers=k) as pool:
         for scene_type in benchmark_cfg["dataset"]["scene_types"]:

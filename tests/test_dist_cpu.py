@@ -31,13 +31,13 @@ def _worker(rank, world, port, q):
     vols = np.array([5.0, 3.0, 9.0, 3.0, 7.0, 2.5, 8.0, 2.5, 6.0, 4.0, 1.5, 1.5, 9.0])  # global min 1.5 first at row 10
     trajs = np.arange(total)[:, None, None] * np.ones((total, 7, 50))
     li = int(np.argmin(vols[lo:hi]))
-    res = ED.gather_best(float(vols[lo + li]), li, trajs[lo + li], success=(rank == 1), rows_ok=3 + rank, rows=hi - lo)
+    res = ED.gather_best(float(vols[lo + li]), li, trajs[lo + li], success=(rank == 1), rows_ok=3 + rank, rows=hi - lo, collision_free=True, rows_collision_free=4 + rank)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     ED.allreduce_sum_(t)
     cfgs = cfgs_for([1, 10, 11], 4)
     sh = ED.shard_guide_cfgs(cfgs, *ED.shard_rows(12, rank, world))
     q.put((rank, lo, hi, res["rank"], res["index"], res["volume"], float(res["traj"][0, 0]), res["n_success"], float(t.item()),
-           sh["total_batch_size"], sh["guidance_method"].tolist(), res["rows_ok"], res["rows"], res["success"]))
+           sh["total_batch_size"], sh["guidance_method"].tolist(), res["rows_ok"], res["rows"], res["success"], res["rows_collision_free"], res["collision_free"]))
     dist.destroy_process_group()
 
 
@@ -61,7 +61,8 @@ def test_shard_and_gather_world2():
     assert rest0[6] == 6 and rest1[6] == 6
     assert rest0[7] == [0, 0, 0, 0, 1, 1] and rest1[7] == [1, 1, 1, 1, 1, 1]
     # batch success counts come back summed over the ranks (3 + 4 of 6 + 7 rows); `success` is the winning row's flag (rank 1's)
-    assert rest0[8:] == rest1[8:] == [7, 13, True]
+    # the reference's criterion (collision-free, limits not required) travels beside the strict one: 4 + 5 rows, winning row's flag
+    assert rest0[8:] == rest1[8:] == [7, 13, True, 9, True]
 
 
 def test_gather_single_process_passthrough():
@@ -70,7 +71,9 @@ def test_gather_single_process_passthrough():
     r = ED.gather_best(0.25, 3, np.ones((7, 50)), True)
     assert r["rank"] == 0 and r["index"] == 3 and r["volume"] == 0.25 and r["n_success"] == 1 and (r["rows_ok"], r["rows"]) == (0, 0)
     r = ED.gather_best(0.25, 3, np.ones((7, 50)), False, rows_ok=17, rows=1024)
-    assert (r["rows_ok"], r["rows"], r["success"]) == (17, 1024, False)
+    assert (r["rows_ok"], r["rows"], r["success"]) == (17, 1024, False) and r["collision_free"] is False  # callers without the split: strict flag for both
+    r = ED.gather_best(0.25, 3, np.ones((7, 50)), False, rows_ok=17, rows=1024, collision_free=True, rows_collision_free=40)
+    assert (r["success"], r["collision_free"], r["rows_collision_free"]) == (False, True, 40)
     assert ED.shard_rows(1024, 3, 8) == (384, 512)
 
 

@@ -613,7 +613,50 @@ def test_infer_serial_driver_c1():
     res = infer_serial.run(os.path.join(root, "configs", "cfg_c1_plumbing.yaml"), dataset=ds, verbose=False)
     oc = ds.fetch_data(0, "stress")[0]
     ref = SO.success_rows(res[0]["trajectory"][None], oc, kinds=np.array([0, 0, 0, 0, 1, 1]))
-    assert res[0]["success_proxy"] == int(ref["ok"][0]) and res[0]["first_collision_waypoint"] == int(ref["first"][0])
+    # the driver tallies the REFERENCE's flag (no contact; lib/environment.py:672) and reports the strict one (also inside the limits) beside it
+    assert res[0]["success_proxy"] == int(ref["first"][0] < 0) and res[0]["success_strict"] == int(ref["ok"][0]) and res[0]["first_collision_waypoint"] == int(ref["first"][0])
+    assert res[0]["rows_ok"] <= res[0]["rows_collision_free"] <= res[0]["rows"]
+
+
+def test_infer_serial_on_a_converted_problem_set(tmp_path):
+    """a problem-set JSON in the format scripts/mpinets_pkl_to_json.py writes from an MPiNets pickle (cuboids +
+    true cylinders, quaternions w-first, goals as an explicit input) drives the reference-shaped scene loop through
+    scenes.ProblemSetDataset; the success check sees the cylinders as cylinders.  (The pickle -> JSON half is a CPU test.)"""
+    import json
+    import os
+
+    import yaml
+
+    import infer_serial
+    from edmp_amd import franka, scenes
+    from oracle import success_oracle as SO
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lo, hi = franka.joint_limits()
+    rs = np.random.RandomState(9)
+    problems = []
+    for k in range(2):
+        oc = scenes.random_scene(20 + k, 6)
+        to_wxyz = lambda o: [float(o[6]), float(o[3]), float(o[4]), float(o[5])]  # noqa: E731
+        problems.append({"cuboids": [{"center": o[:3].tolist(), "quaternion_wxyz": to_wxyz(o), "dims": o[7:10].tolist()} for o in oc[:4]],
+                         "cylinders": [{"center": o[:3].tolist(), "quaternion_wxyz": to_wxyz(o), "radius": float(o[7]), "height": float(o[9])} for o in oc[4:]],
+                         "start": rs.uniform(lo, hi).tolist(), "target": {"xyz": [0.4, 0.0, 0.4], "quaternion_wxyz": [0, 1, 0, 0], "frame": "right_gripper"},
+                         "goals": rs.uniform(lo, hi, (20, 7)).tolist()})
+    pj = tmp_path / "problems.json"
+    json.dump({"format": "edmp_amd problem set v1", "scene_types": {"tabletop": problems}}, open(pj, "w"))
+    cfg = yaml.safe_load(open(os.path.join(root, "configs", "cfg_c1_plumbing.yaml")))
+    cfg["dataset"]["scene_types"] = ["tabletop"]
+    os.makedirs(tmp_path / "cfgs")
+    cj = tmp_path / "cfgs" / "cfg_problem_set.yaml"
+    yaml.safe_dump(cfg, open(cj, "w"))
+    ds = scenes.ProblemSetDataset(str(pj))
+    res = infer_serial.run(str(cj), dataset=ds, verbose=False)
+    assert len(res) == 2 and all(r["scene_type"] == "tabletop" and np.isfinite(r["trajectory"]).all() for r in res)
+    for k, r in enumerate(res):
+        oc = ds.fetch_data(k, "tabletop")[0]
+        ref = SO.success_rows(r["trajectory"][None], oc, kinds=np.array([0, 0, 0, 0, 1, 1]))
+        assert r["success_proxy"] == int(ref["first"][0] < 0) and r["first_collision_waypoint"] == int(ref["first"][0])
+        assert np.array_equal(r["trajectory"][:, 0], np.asarray(problems[k]["start"]))  # conditioned on the problem's own start
 
 
 def test_infer_serial_two_scenes_in_flight():
@@ -1137,8 +1180,41 @@ def test_bench_two_ranks_under_torchrun(mode):
     d = _run_bench_under_torchrun(extra)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2048 and d["steps"] == 1 and d["scaling"] == "weak"
     assert math.isfinite(d["value"]) and d["value"] > 0 and abs(d["value"] - 2048 * 255 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
-    assert d["success_proxy"]["rows"] == 2048 and 0 <= d["success_proxy"]["rows_ok"] <= 2048
+    sp = d["success_proxy"]
+    assert sp["rows"] == 2048 and 0 <= sp["rows_ok"] <= sp["rows_collision_free"] <= 2048 and sp["collision_free_rate"] == sp["rows_collision_free"] / 2048
+    assert d["n_ranks_seen"] == 2
     assert ("logical batch" in d["config"]["parallelism"]) == (mode == "logical_batch")
+
+
+def test_bench_plain_launch_with_gpus_2_spawns_two_ranks():
+    """`python bench.py --gpus 2` started WITHOUT torch.distributed.run must not fall through to one rank and
+    print a mislabelled line: it re-execs itself under the launcher (gloo over the one GPU of a test box, RCCL with two) and the
+    line reports the world size the process group summed (`n_ranks_seen`).  With too few GPUs and the RCCL backend it refuses."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from tests.conftest import ROOT
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    few = torch.cuda.device_count() < 2
+    if few:
+        refuse = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline"],
+                                cwd=ROOT, env={**env, "EDMP_DIST_BACKEND": "nccl"}, capture_output=True, text=True, timeout=300)
+        assert refuse.returncode != 0 and "GPU(s) visible" in refuse.stderr and not [l for l in refuse.stdout.splitlines() if l.startswith("{")]
+        env["EDMP_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["config"]["global_batch"] == 2048
+    assert d["dist_backend"] == ("gloo" if few else "nccl")
 
 
 def test_allreduce_hook_inside_the_device_loop(tiny_net):

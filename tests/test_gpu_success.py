@@ -210,3 +210,49 @@ def test_success_error_behaviour():
         g.success_rows(np.zeros((2, 7, 50)), substeps=65)
     with pytest.raises(_capi.EdmpError):
         g.success_rows(np.zeros((2, 7, 1)))
+
+
+def test_success_kernel_worst_case_cost_on_a_collision_free_batch():
+    """the kernel leaves a row's obstacle loop at the first hit, so a batch that collides everywhere (random-init
+    weights: 0 / 1024) is its EASY case.  The worst case is a collision-free batch inside the limits (what trained weights should
+    produce): every one of the 197 configurations x 9 link boxes x 16 obstacles is tested, 3 of them as true cylinders.  Asserted:
+    every row passes under both criteria, and 1024 rows cost < 2 ms (< 0.8 % of a 267 ms scene); the measured time is printed
+    (DESIGN.md §5 quotes it) and also reported by bench.py (`success_proxy.check_ms`)."""
+    import torch
+
+    from edmp_amd import franka, scenes
+
+    rs = np.random.RandomState(3)
+    lo, hi = franka.joint_limits()
+    B, N = 1024, 50
+    scene = scenes.random_scene(11, 16)
+    scene[:, 0] += 10.0  # the whole scene 10 m away: nothing can touch the arm (reach < 1.2 m)
+    kinds = np.zeros(16, dtype=np.int32)
+    kinds[[2, 7, 11]] = 1
+    scene[kinds == 1, 8] = scene[kinds == 1, 7]
+    X = _rows(rs, B, N, lo + 0.05, hi - 0.05, spread=0.5)
+    X = np.clip(X, lo[None, :, None] + 1e-3, hi[None, :, None] - 1e-3)
+    g = _guide(scene, B, kinds)
+    Xd = torch.from_numpy(X).to(DEV)
+    res = g.success_rows(Xd)
+    assert res["rows_ok"] == res["rows_collision_free"] == res["rows_within"] == B and res["ok"].all() and (res["first"] == -1).all()
+    st = g.ctx.stream
+    times = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        g.success_rows(Xd, return_device=True)
+        e1.record(st)
+        e1.synchronize()
+        times.append(e0.elapsed_time(e1))
+    ms = min(times)
+    # the same rows against the scene where it stands: rows that collide leave early
+    g2 = _guide(scenes.random_scene(11, 16), B)
+    g2.success_rows(Xd)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    r2 = g2.success_rows(Xd, return_device=True)
+    e1.record(st)
+    e1.synchronize()
+    print(f"[success kernel] 1024 rows x 16 obstacles: collision-free batch {ms:.3f} ms (worst case), batch with {B - r2['rows_collision_free']} colliding rows {e0.elapsed_time(e1):.3f} ms")
+    assert ms < 2.0, ms

@@ -248,3 +248,22 @@ def test_product_never_imports_the_oracle():
             assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
     drv = open(os.path.join(ROOT, "infer_serial.py")).read() if os.path.exists(os.path.join(ROOT, "infer_serial.py")) else ""
     assert not re.search(r"^\s*(from|import)\s+oracle", drv, flags=re.M)
+
+
+def test_bench_refuses_a_multi_gpu_run_it_cannot_honour():
+    """`bench.py --gpus N` must not be able to print a mislabelled single-rank line.  Without enough
+    visible GPUs (none in the build container) and the RCCL backend it exits non-zero before anything is measured; a
+    WORLD_SIZE that disagrees with --gpus is refused too.  (The re-exec under torch.distributed.run is a -m gpu test.)"""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the refusal path is not reachable here")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "EDMP_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr and "{" not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env={**env, "WORLD_SIZE": "4", "EDMP_DIST_BACKEND": "gloo"}, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and "{" not in r.stdout
