@@ -301,9 +301,9 @@ def main():
     if world == 1 and rank == 0 and not logical and not args.no_two_scenes:
         import threading
 
-        from edmp_amd.runtime import Context
+        from edmp_amd.runtime import lane_context
 
-        ctx2 = Context(dev_index)
+        ctx2 = lane_context(dev_index, 1)
         net2 = TemporalUNet(None, C, 32, ctx2, dims=FULL_DIMS, seed=1, max_batch=B)
         guide2 = IntersectionVolumeGuide(scenes.random_scene(12, args.obstacles), ctx2, cfgs, B)
         dif2 = Diffusion(T, ctx2)

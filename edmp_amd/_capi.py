@@ -23,7 +23,14 @@ class UNetDesc(C.Structure):
 
 
 class EdmpError(RuntimeError):
-    pass
+    rc = None  # status code of the failing C-ABI call (include/edmp_hip.h), None for errors raised on the Python side
+
+
+class EdmpLayoutError(EdmpError):
+    """EDMP_ERR_LAYOUT: a packed weight image written by another library version or under other builder switches"""
+
+
+ERR_LAYOUT = -4
 
 
 _vp, _i, _d = C.c_void_p, C.c_int, C.c_double
@@ -110,7 +117,9 @@ def load():
 def check(rc: int, what: str = ""):
     if rc != 0:
         msg = load().edmp_last_error()
-        raise EdmpError(f"{what or 'libedmp_hip'} failed (rc={rc}): {msg.decode() if msg else '?'}")
+        err = (EdmpLayoutError if rc == ERR_LAYOUT else EdmpError)(f"{what or 'libedmp_hip'} failed (rc={rc}): {msg.decode() if msg else '?'}")
+        err.rc = rc
+        raise err
 
 
 def as_pd(a):

@@ -533,13 +533,14 @@ __global__ __launch_bounds__(256, (SB <= 2 ? 2 : 1)) void level_kernel(const flo
 
 template <int MODE, int C, int L, int SB, int CIN>
 int launch_level_t(const LevelP& p, hipStream_t s) {
-    static bool attr_set = false;
+    // set once per instance; launches come from several host threads (two contexts: scenes in flight, chains of one batch)
+    static std::atomic<int> attr_set{0};
     EDMP_REQUIRE(p.C1 + p.C2 == CIN && p.C1 % 4 == 0 && p.C2 % 4 == 0, "level kernel built for %d stored input channels, got %d + %d", CIN, p.C1, p.C2);
     constexpr size_t bytes = LevelCfg<MODE, C, L, SB, CIN>::lds_bytes();
     static_assert(bytes <= 160 * 1024, "level kernel exceeds the 160 KiB LDS of a CU");
-    if (!attr_set) {
+    if (!attr_set.load(std::memory_order_acquire)) {  // idempotent call: a second thread racing here at worst repeats it
         EDMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&level_kernel<MODE, C, L, SB, CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        attr_set = true;
+        attr_set.store(1, std::memory_order_release);
     }
     hipLaunchKernelGGL((level_kernel<MODE, C, L, SB, CIN>), dim3((p.B + SB - 1) / SB), dim3(256), bytes, s, p.src1, p.src2, p.w11, p.C1, p.C2, p.B, p);
     return EDMP_OK;

@@ -18,6 +18,7 @@
  * C ABI (ctypes binding in edmp_amd/nprng.py); host only, no GPU involved. */
 #define _GNU_SOURCE
 #include <math.h>
+#include <pthread.h>
 #include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -97,16 +98,18 @@ static inline int attempt(const uint32_t* w, double* v) {
 /* attempts per block (16 bytes of words + 16 bytes of candidate pairs each): 2^15 keeps the two word blocks and the
  * candidate pairs (1.5 MiB) inside the cache the team shares - measured on the GPU box (EPYC 9575F, 8 threads on one CCD):
  * 1.5 ns per normal at 2^15 against 2.2 at 2^18.  EDMP_NPRNG_BLOCK=<log2> overrides. */
-static int64_t block_att(void) {
-    static int64_t v = 0;
-    if (!v) {
-        const char* e = getenv("EDMP_NPRNG_BLOCK");
-        int lg = e ? atoi(e) : 15;
-        if (lg < 10) lg = 10;
-        if (lg > 22) lg = 22;
-        v = (int64_t)1 << lg;
-    }
-    return v;
+static int64_t g_block_att = 0;
+static pthread_once_t g_block_once = PTHREAD_ONCE_INIT;
+static void block_att_init(void) {
+    const char* e = getenv("EDMP_NPRNG_BLOCK");
+    int lg = e ? atoi(e) : 15;
+    if (lg < 10) lg = 10;
+    if (lg > 22) lg = 22;
+    g_block_att = (int64_t)1 << lg;
+}
+static int64_t block_att(void) { /* two contexts draw from two host threads: initialised exactly once */
+    (void)pthread_once(&g_block_once, block_att_init);
+    return g_block_att;
 }
 #define BLOCK_ATT (block_att())
 #define MAX_THREADS 256
@@ -145,8 +148,8 @@ static int parse_cpu_list(const char* txt, cpu_set_t* set) {
     return n;
 }
 
-static void pick_domain(void) {
-    if (g_domain_state) return;
+static pthread_once_t g_domain_once = PTHREAD_ONCE_INIT;
+static void pick_domain_once(void) {
     g_domain_state = -1;
     const char* pin = getenv("EDMP_NPRNG_PIN");
     if (pin && atoi(pin) == 0) return;
@@ -187,6 +190,10 @@ static void pick_domain(void) {
     g_domain_cores = cores > 0 ? cores : n;
     g_domain_state = 1;
 }
+/* every caller sees the finished decision (0 is never observable after this returns): with a plain lazy static a second
+ * draw thread could read the intermediate -1 and run unpinned */
+static void pick_domain(void) { (void)pthread_once(&g_domain_once, pick_domain_once); }
+
 
 /* number of threads a draw will actually use for `requested`, and the size of the cache domain (0: not pinned) */
 int edmp_nprng_team(int requested, int* domain_cores) {
@@ -290,7 +297,11 @@ int edmp_nprng_standard_normal(uint32_t* key, int* pos, int* has_gauss, double* 
 #else
             const int t = 0, nt = 1;
 #endif
-            if (pinned) (void)sched_setaffinity(0, sizeof(g_domain), &g_domain); /* this thread only; pool threads keep it */
+            /* this thread only, and only for this call: libgomp keeps the team of a master thread alive, and other OpenMP
+             * work started from the same thread (torch, NumPy) would otherwise inherit workers confined to one L3 domain */
+            cpu_set_t my_mask;
+            const int my_pinned = pinned && sched_getaffinity(0, sizeof(my_mask), &my_mask) == 0;
+            if (my_pinned) (void)sched_setaffinity(0, sizeof(g_domain), &g_domain);
             /* consumers: all threads when alone, otherwise threads 1..nt-1 */
             const int nc = nt > 1 ? nt - 1 : 1, c = nt > 1 ? t - 1 : 0;
             if (t == 0) nt_used = nt;
@@ -336,11 +347,12 @@ int edmp_nprng_standard_normal(uint32_t* key, int* pos, int* has_gauss, double* 
                 } /* implicit barrier */
                 if (!cont) break;
             }
+            if (my_pinned) (void)sched_setaffinity(0, sizeof(my_mask), &my_mask);
         }
         if (nt_used > 1) st = saved; /* drop the speculative block */
     }
     free(words2);
-    if (pinned) (void)sched_setaffinity(0, sizeof(caller_mask), &caller_mask); /* the caller's own placement is not ours to keep */
+    if (pinned) (void)sched_setaffinity(0, sizeof(caller_mask), &caller_mask); /* (the master restored its mask inside the region; kept as a safety net) */
     tail_exact(&st, has_gauss, gauss, out, o, n, words, cand, ok);
     free(words);
     free(cand);

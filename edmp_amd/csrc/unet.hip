@@ -1244,11 +1244,11 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
     u->layout = pk.layout_id(kPackVersion);
     if (packed && packed_layout != u->layout) {
         set_error("packed weight image has layout id %d, this library with the current builder switches packs %d: re-pack from the state dict", packed_layout, u->layout);
-        return EDMP_ERR_ARG;
+        return EDMP_ERR_LAYOUT;
     }
     if (packed && (int64_t)pk.total != n_packed) {
         set_error("packed weight image has %lld floats, this architecture / library layout needs %zu", (long long)n_packed, pk.total);
-        return EDMP_ERR_ARG;
+        return EDMP_ERR_LAYOUT;
     }
     if (hipMalloc((void**)&u->wpack, pk.total * sizeof(float)) != hipSuccess) {
         set_error("hipMalloc of %zu weight bytes failed", pk.total * sizeof(float));

@@ -776,12 +776,13 @@ inline int xcd_split(int ng, int nt, double w_elems, double a_elems) {
 
 template <int KIND, int MS, int CG, int GS, int LIN, bool RES>
 int launch_wide_t(const RcbP& p, hipStream_t s) {
-    static bool attr_set = false;
+    // set once per instance; launches come from several host threads (two contexts: scenes in flight, chains of one batch)
+    static std::atomic<int> attr_set{0};
     constexpr size_t bytes = WideCfg<KIND, MS, CG, GS, LIN, RES>::lds_bytes();
     static_assert(bytes <= 160 * 1024, "position-tile conv kernel exceeds the 160 KiB LDS of a CU");
-    if (!attr_set) {
+    if (!attr_set.load(std::memory_order_acquire)) {  // idempotent call: a second thread racing here at worst repeats it
         EDMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_conv_kernel<KIND, MS, CG, GS, LIN, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        attr_set = true;
+        attr_set.store(1, std::memory_order_release);
     }
     const int ng = p.Cout / CG, nt = (p.B + MS - 1) / MS;
     EDMP_REQUIRE(p.C2 == 0 || p.C2 == p.C1, "wide_conv_kernel: the two halves of a concatenated input must have the same width (C1=%d, C2=%d)", p.C1, p.C2);

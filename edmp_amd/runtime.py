@@ -41,6 +41,35 @@ class Context:
         self.bound_guide = None
         self.sampler_T = None
 
+    def close(self):
+        """release everything the context holds on the GPU and the host: edmp_ctx_destroy (resident models and guides, activation
+        buffers, sampler state, streams), the pinned staging ring and the draw thread.  Objects bound to a closed context must not
+        be used again.  Contexts obtained from get_context / lane_context are cached for the life of the process and normally
+        never closed; a caller that creates `Context(i)` itself owns it and closes it."""
+        if getattr(self, "h", None) is None:
+            return
+        pool = getattr(self, "_draw_pool", None)
+        if pool is not None:
+            pool.shutdown(wait=True)
+            self._draw_pool = None
+        try:
+            self.stream.synchronize()
+        finally:
+            self.lib.edmp_ctx_destroy(self.h)
+            self.h = None
+            self.bound_model = self.bound_guide = None
+            self._pinned = None
+            for key in [k for k, v in _contexts.items() if v is self] + [k for k, v in _lane_contexts.items() if v is self]:
+                _contexts.pop(key, None)
+                _lane_contexts.pop(key, None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     # ---- helpers ---------------------------------------------------------------------------------------------
     def to_dev(self, arr, dtype) -> torch.Tensor:
         """host ndarray / tensor -> contiguous device tensor on this context's stream."""
@@ -180,6 +209,23 @@ def get_context(device) -> Context:
     if idx not in _contexts:
         _contexts[idx] = Context(idx)
     return _contexts[idx]
+
+
+_lane_contexts: dict = {}
+
+
+def lane_context(device, lane: int) -> Context:
+    """the context of lane `lane` of a GPU: lane 0 is get_context(device), lanes >= 1 are further contexts of the same device
+    (own stream, own resident model and guides) for several scenes in flight.  Cached per (device, lane): repeated
+    infer_serial.run(scenes_in_flight=k) calls reuse the lanes instead of leaking a resident UNet, activation buffers, streams
+    and a pinned ring per call."""
+    base = get_context(device)
+    if lane <= 0:
+        return base
+    key = (base.index, int(lane))
+    if key not in _lane_contexts:
+        _lane_contexts[key] = Context(base.index)
+    return _lane_contexts[key]
 
 
 def ptr(t: torch.Tensor) -> C.c_void_p:

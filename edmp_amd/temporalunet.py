@@ -51,10 +51,14 @@ class TemporalUNet:
                 self._packed = pk
                 try:
                     self._bind()
-                except _capi.EdmpError:
+                except _capi.EdmpLayoutError as e:
+                    # ONLY a layout mismatch falls back to the state dict (stale image / other builder switches); an allocation
+                    # or HIP failure is a real error and propagates instead of being retried and masked
                     self._packed = None
                     if not os.path.exists(ck):
                         raise
+                    print(f"[edmp_amd] {os.path.join(model_name, weights.PACKED_NAME)} does not match this library's packing ({e}); loading "
+                          f"weights_latest.pt instead - re-pack with TemporalUNet.pack()")
                 else:
                     self.losses = np.load(os.path.join(model_name, "losses.npy")) if os.path.exists(os.path.join(model_name, "losses.npy")) else np.array([])
                     print("Loaded Model at " + str(self.losses.size) + " epochs")

@@ -26,6 +26,7 @@ extern "C" {
 #define EDMP_ERR_ARG (-1)
 #define EDMP_ERR_HIP (-2)
 #define EDMP_ERR_STATE (-3)
+#define EDMP_ERR_LAYOUT (-4) /* edmp_unet_load_packed: the image was packed by another library version / under other builder switches */
 
 #define EDMP_MAX_LEVELS 8
 #define EDMP_N_JOINTS 7

@@ -34,7 +34,7 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=
     from concurrent.futures import ThreadPoolExecutor
 
     from edmp_amd.diffusion import draw_noise
-    from edmp_amd.runtime import Context, get_context
+    from edmp_amd.runtime import get_context, lane_context
 
     benchmark_cfg = GC.load_yaml(cfg_path)
     device = benchmark_cfg["model"]["device"]
@@ -56,7 +56,7 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=
     base = get_context(device)
     lanes = []  # one (context, diffuser, denoiser) per scene in flight; the weights are replicated per context
     for j in range(k):
-        ctx = base if j == 0 else Context(base.index)
+        ctx = lane_context(base, j)  # lane 0 = the device's context; further lanes are cached per (device, lane), not re-created per call
         lanes.append((Diffusion(T=T, device=ctx), TemporalUNet(model_name=model_name, input_dim=num_channels, time_dim=32, dims=(32, 64, 128, 256, 512, 512),
                                                                 device=ctx, max_batch=total_batch_size)))
 

@@ -1446,3 +1446,28 @@ def test_karatsuba_forms_with_adversarial_weights(oracle, monkeypatch, kind):
     assert rmse(kar, ref32) <= 2e-5 and maxabs(kar, ref32) <= 2e-4, (kind, rmse(kar, ref32), maxabs(kar, ref32))
     assert rmse(direct, ref32) <= 2e-5 and maxabs(direct, ref32) <= 2e-4, (kind, rmse(direct, ref32), maxabs(direct, ref32))
     assert e_k <= 3.0 * max(e_d, e_t), (kind, e_k, e_d, e_t)
+
+
+def test_context_close_releases_the_gpu_and_lanes_are_cached():
+    """secondary contexts (scenes in flight) used to leak a resident UNet + activation buffers + streams per
+    infer_serial.run call.  Lanes are now cached per (device, lane) and an explicitly created Context can be closed."""
+    from edmp_amd import _capi
+    from edmp_amd.runtime import Context, lane_context
+    from edmp_amd.temporalunet import TemporalUNet
+
+    assert lane_context(DEV, 1) is lane_context(DEV, 1) and lane_context(DEV, 0) is not lane_context(DEV, 1)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    with Context(0) as ctx:
+        net = TemporalUNet(None, 7, 32, ctx, dims=(32, 64, 128, 256, 512, 512), seed=3, max_batch=256)
+        y = net(torch.randn(256, 7, 50, device=DEV), torch.tensor([7.0]))
+        assert torch.isfinite(y).all()
+        free1, _ = torch.cuda.mem_get_info()
+        assert free0 - free1 > 90e6  # the 92 MB weight image + activations live in the context
+        del y
+    free2, _ = torch.cuda.mem_get_info()
+    assert free0 - free2 < 0.25 * (free0 - free1), (free0, free1, free2)  # edmp_ctx_destroy gave the library's allocations back
+    assert ctx.h is None
+    ctx.close()  # idempotent
+    with pytest.raises((_capi.EdmpError, Exception)):
+        net(torch.randn(4, 7, 50, device=DEV), torch.tensor([7.0]))
