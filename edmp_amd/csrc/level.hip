@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256, (SB <= 2 ? 2 : 1)) void level_kernel(const flo
                         for (int q = 0; q < C / 4; ++q) hv[q] = *reinterpret_cast<const float4*>(TY + tid * RSC + 4 * q);
                         const TailP& tl = p.tail;
                         const int b = b0 + tail_sm, pos = tail_pos, i = b * LOUT + pos;
-#define EDMP_TAIL(FIN, RN) head_psample_item<FIN, RN, C>(hv, tail_x, tail_z, i, b, pos, TW, TW + 8 * C, tl.X, nullptr, tl.xin, tl.sg, LOUT, tl.C, tl.c1, tl.sqrt_alpha, tl.beta, tl.zero_row0, tl.seed, tl.rng_step, tl.cond)
+#define EDMP_TAIL(FIN, RN) head_psample_item<FIN, RN, C>(hv, tail_x, tail_z, i, b, pos, TW, TW + 8 * C, tl.X, nullptr, tl.xin, tl.sg, LOUT, tl.C, tl.c1, tl.sqrt_alpha, tl.beta, tl.zero_row0, tl.seed, tl.rng_step, tl.cond, tl.elem0)
                         if (tl.finish) {
                             if (tl.rng) EDMP_TAIL(true, true);
                             else EDMP_TAIL(true, false);

@@ -133,6 +133,9 @@ struct Op {
     int wrs_kind; // OP_WRS: WK_DOWN / WK_UP
     int tb_off;   // GN: offset into the time-bias row, -1 if none
     int branch;   // 0 = main stream; 1 = fork point (record before this op); 2 = runs on the side stream; 3 = join (wait) before this op
+    // floats per batch row of the op's tensors (all activations are [B][L][C]): a launch over the rows [r0, r0 + n) of the batch
+    // - one chain of a row-sharded run - is the same launch with every tensor pointer advanced by r0 rows
+    size_t rs_src1, rs_src2, rs_dst, rs_res, rs_resout;
     double flops_nominal, flops_exec;  // per trajectory: every tap | MFMA work actually issued (padding taps skipped, Karatsuba forms)
     double flops_direct;               // per trajectory: the direct form with padding taps skipped (round-1 'executed' accounting)
     char name[64];                     // kernel instance as rocprofv3 prints it (without the edmp:: prefix)
@@ -1381,6 +1384,14 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
             g.C = o.C;
             op.tb_off = o.tb_off;
         }
+        if (o.kind == OP_GN) {
+            op.rs_dst = op.rs_res = (size_t)o.L * o.C;
+        } else {
+            op.rs_src1 = (size_t)o.Lin * o.C1;
+            op.rs_src2 = (size_t)o.Lin * o.C2;
+            op.rs_dst = (size_t)o.Lout * o.Cout;
+            op.rs_res = op.rs_resout = (size_t)o.Lin * o.Cout;  // OP_RCB: residual addend / folded residual output; OP_LVL: the skip tensor
+        }
         op_kernel_name(op, op.name);
         u->prog.push_back(op);
     }
@@ -1426,11 +1437,16 @@ namespace edmp {
 // run the layer program on u->x_in ([B][N][8], already filled); leaves the head input in u->h_last
 // `tail` (device-resident loop): if the program ends with the fused final level (LV_UP_FINAL, 32 channels into the head) the
 // tail of the reverse step runs inside that launch and *tail_done is set; otherwise the caller launches head_psample_kernel
-int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_done) {
+// `r0`, `run_stream`: the rows [r0, r0 + B) of the batch on another stream (one chain of a row-sharded run, sampler.hip); the
+// caller has offset the tail's pointers likewise.  Row ranges are independent (a workgroup never mixes samples of different tiles
+// in one reduction), so the chains' results are bit-identical to the single launch over all rows.
+int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_done, int r0, hipStream_t run_stream) {
     if (tail_done) *tail_done = false;
     UNet* u = ctx->unet;
     EDMP_REQUIRE(u, "edmp_unet_load has not been called");
-    EDMP_REQUIRE(B >= 1 && B <= u->max_batch, "batch %d outside 1..max_batch=%d", B, u->max_batch);
+    EDMP_REQUIRE(B >= 1 && r0 >= 0 && r0 + B <= u->max_batch, "rows %d..%d outside 0..max_batch=%d", r0, r0 + B, u->max_batch);
+    hipStream_t main_stream = run_stream ? run_stream : ctx->stream;
+    EDMP_REQUIRE(r0 == 0 || !ctx->prof.on, "per-launch event brackets are recorded for whole-batch runs only");
     EDMP_REQUIRE(t >= 1 && t <= u->desc.T, "t=%d outside 1..T=%d", t, u->desc.T);
     const float* trow = u->tbias + (size_t)(t - 1) * u->tb_stride;
     Prof& pf = ctx->prof;
@@ -1444,19 +1460,20 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
             EDMP_HIP_CHECK(hipEventCreate(&whole.a));
             EDMP_HIP_CHECK(hipEventCreate(&whole.b));
         }
-        EDMP_HIP_CHECK(hipEventRecord(whole.a, ctx->stream));
+        EDMP_HIP_CHECK(hipEventRecord(whole.a, main_stream));
     }
     int op_index = -1;
     for (const Op& op : u->prog) {
         ++op_index;
-        hipStream_t s = ctx->stream;
+        hipStream_t s = main_stream;
+        EDMP_REQUIRE(!(run_stream && op.branch), "the side-stream build of the layer program (EDMP_SIDE_STREAM) cannot run as row chains");
         if (op.branch == 1) {
-            EDMP_HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
+            EDMP_HIP_CHECK(hipEventRecord(ctx->ev_fork, main_stream));
         } else if (op.branch == 2) {
             s = ctx->side_stream;
             EDMP_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_fork, 0));
         } else if (op.branch == 3) {
-            EDMP_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+            EDMP_HIP_CHECK(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
         }
         Prof::Pend ev{nullptr, nullptr, op_index};
         const bool timed = pf.on == 1 && op.kind != OP_GN;
@@ -1475,15 +1492,25 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
         if (op.kind == OP_RCB) {
             RcbP p = op.rc;
             p.B = B;
+            p.src1 += r0 * op.rs_src1;
+            if (p.src2) p.src2 += r0 * op.rs_src2;
+            p.dst += r0 * op.rs_dst;
+            if (p.add_res) p.add_res += r0 * op.rs_res;
+            if (p.res_out) p.res_out += r0 * op.rs_resout;
             p.add_tb = op.tb_off >= 0 ? trow + op.tb_off : nullptr;
             EDMP_REQUIRE(!(p.add_tb && p.add_res), "fused conv block: a launch adds the time bias (conv1) or the residual (conv2), not both");
             rc = launch_rcb(p, op.rc_L, op.rc_form, s);
         } else if (op.kind == OP_LVL) {
             LevelP p = op.lv;
             p.B = B;
+            const bool out_is_head_input = p.out == u->h_last;
+            p.src1 += r0 * op.rs_src1;
+            if (p.src2) p.src2 += r0 * op.rs_src2;
+            if (p.skip_out) p.skip_out += r0 * op.rs_res;
+            p.out += r0 * op.rs_dst;
             p.tb1 = trow + op.lv_tb1;
             p.tb2 = trow + op.lv_tb2;
-            if (tail && tail_done && op.lv_variant == 4 && op_index + 1 == (int)u->prog.size() && u->head_cin == 32 && tail->N == u->desc.horizon && tail->C <= 8 && p.out == u->h_last && u->fuse_tail) {
+            if (tail && tail_done && op.lv_variant == 4 && op_index + 1 == (int)u->prog.size() && u->head_cin == 32 && tail->N == u->desc.horizon && tail->C <= 8 && out_is_head_input && u->fuse_tail) {
                 p.tail = *tail;
                 p.tail.on = 1;
                 p.tail.w = u->head_w;
@@ -1494,14 +1521,21 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
         } else if (op.kind == OP_WRS) {
             RcbP p = op.rc;
             p.B = B;
+            p.src1 += r0 * op.rs_src1;
+            p.dst += r0 * op.rs_dst;
             rc = launch_wrs(p, op.wrs_kind, op.rc_L, s);
         } else if (op.kind == OP_CONV) {
             ConvP p = op.cv;
             p.B = B;
+            p.src1 += r0 * op.rs_src1;
+            if (p.src2) p.src2 += r0 * op.rs_src2;
+            p.dst += r0 * op.rs_dst;
             launch_conv(p, s);
         } else {
             GnP g = op.gn;
             g.B = B;
+            g.y += r0 * op.rs_dst;
+            if (g.add_res) g.add_res += r0 * op.rs_res;
             g.add_tbias = op.tb_off >= 0 ? trow + op.tb_off : nullptr;
             rc = launch_gn(g, s);
         }
@@ -1513,7 +1547,7 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
         if (op.kind == OP_CONV && op.branch == 2) EDMP_HIP_CHECK(hipEventRecord(ctx->ev_join, s));
     }
     if (pf.on == 2) {
-        EDMP_HIP_CHECK(hipEventRecord(whole.b, ctx->stream));
+        EDMP_HIP_CHECK(hipEventRecord(whole.b, main_stream));
         pf.pending.push_back(whole);
     }
     EDMP_HIP_CHECK(hipGetLastError());
@@ -1557,7 +1591,7 @@ int unet_forward_impl(edmp_ctx* ctx, const float* x_dev, int B, int t, float* ep
         int total = B * N * 8;
         hipLaunchKernelGGL(pack_input_kernel, dim3((total + 255) / 256), dim3(256), 0, s, x_dev, u->x_in, B, C, N, 8);
     }
-    int rc = unet_run_program(ctx, B, t, nullptr, nullptr);
+    int rc = unet_run_program(ctx, B, t, nullptr, nullptr, 0, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(head_1x1_kernel, dim3((B * N + 255) / 256), dim3(256), 0, s, u->h_last, u->head_w, u->head_b, eps_dev, B, N,
                        u->head_cin, C);
