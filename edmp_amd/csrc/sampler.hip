@@ -24,6 +24,7 @@ int unet_forward_impl(edmp_ctx* ctx, const float* x_dev, int B, int t, float* ep
 int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_done, int r0, hipStream_t run_stream);
 int guide_raw_gradient_from_X(edmp_ctx* ctx, const double* X_dev, int B, int N, int t, bool reduce, int r0, int r1, int buf, hipStream_t run_stream);
 const double* guide_rowsq(edmp_ctx* ctx, int buf);
+size_t unet_chain_offset(const UNet* u, const float* p, int r0);
 int guide_set_startgoal(edmp_ctx* ctx, const double* start, const double* goal);
 int guide_prepare(edmp_ctx* ctx, int B, int L);
 const float* guide_graw(edmp_ctx* ctx);
@@ -342,7 +343,7 @@ static int step_a(edmp_ctx* ctx, double* X, const double* z, int B, int t, int z
     double* Xs = X + (size_t)r0 * C * N;
     const double* zs = z ? z + (size_t)r0 * C * N : nullptr;
     float* xin = u->x_in + (size_t)r0 * N * 8;
-    const float* hlast = u->h_last + (size_t)r0 * N * u->head_cin;
+    const float* hlast = u->h_last + unet_chain_offset(u, u->h_last, r0);  // the chain's slice of the buffer (unet_run_program)
     const unsigned elem0 = (unsigned)r0 * (unsigned)N;
     const int n = nr * C * N;
     const dim3 grid_bn((nr * N + 255) / 256);

@@ -133,9 +133,7 @@ struct Op {
     int wrs_kind; // OP_WRS: WK_DOWN / WK_UP
     int tb_off;   // GN: offset into the time-bias row, -1 if none
     int branch;   // 0 = main stream; 1 = fork point (record before this op); 2 = runs on the side stream; 3 = join (wait) before this op
-    // floats per batch row of the op's tensors (all activations are [B][L][C]): a launch over the rows [r0, r0 + n) of the batch
-    // - one chain of a row-sharded run - is the same launch with every tensor pointer advanced by r0 rows
-    size_t rs_src1, rs_src2, rs_dst, rs_res, rs_resout;
+
     double flops_nominal, flops_exec;  // per trajectory: every tap | MFMA work actually issued (padding taps skipped, Karatsuba forms)
     double flops_direct;               // per trajectory: the direct form with padding taps skipped (round-1 'executed' accounting)
     char name[64];                     // kernel instance as rocprofv3 prints it (without the edmp:: prefix)
@@ -674,6 +672,12 @@ static void op_kernel_name(const Op& op, char* out) {
         const int n = (op.gn.C / 8) * op.gn.L;
         snprintf(out, 64, "gn_mish_kernel<%d>", n <= 128 ? 2 : n <= 256 ? 4 : 8);
     }
+}
+
+// float offset of the first row of a chain that starts at batch row r0, for a tensor living in buffer `p` (unet_run_program)
+size_t unet_chain_offset(const UNet* u, const float* p, int r0) {
+    if (p == u->x_in) return (size_t)r0 * u->desc.horizon * 8;  // dense [B][N][8], shared with the sampler kernels
+    return (size_t)r0 * (u->buf_cap / (size_t)u->max_batch);
 }
 
 bool unet_complete(const UNet* u) { return u && u->wpack && u->tbias && !u->prog.empty(); }
@@ -1384,14 +1388,6 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
             g.C = o.C;
             op.tb_off = o.tb_off;
         }
-        if (o.kind == OP_GN) {
-            op.rs_dst = op.rs_res = (size_t)o.L * o.C;
-        } else {
-            op.rs_src1 = (size_t)o.Lin * o.C1;
-            op.rs_src2 = (size_t)o.Lin * o.C2;
-            op.rs_dst = (size_t)o.Lout * o.Cout;
-            op.rs_res = op.rs_resout = (size_t)o.Lin * o.Cout;  // OP_RCB: residual addend / folded residual output; OP_LVL: the skip tensor
-        }
         op_kernel_name(op, op.name);
         u->prog.push_back(op);
     }
@@ -1440,6 +1436,11 @@ namespace edmp {
 // `r0`, `run_stream`: the rows [r0, r0 + B) of the batch on another stream (one chain of a row-sharded run, sampler.hip); the
 // caller has offset the tail's pointers likewise.  Row ranges are independent (a workgroup never mixes samples of different tiles
 // in one reduction), so the chains' results are bit-identical to the single launch over all rows.
+// Where a chain's rows live: activation buffers are recycled between layers of different (L, C), and concurrent chains are at
+// different layers - so a chain does NOT use rows r0.. of the dense [B][L][C] tensor (chain A's rows of a wide tensor would
+// overlap chain B's rows of a narrow one in the same buffer) but its own slice of every buffer: a dense [B_chain][L][C] tensor at
+// float offset r0 * (buffer capacity per batch row).  The UNet input x_in is the exception: never recycled, written by the
+// sampler kernels with whole-batch indices, so it keeps the dense layout (unet_chain_offset).
 int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_done, int r0, hipStream_t run_stream) {
     if (tail_done) *tail_done = false;
     UNet* u = ctx->unet;
@@ -1462,6 +1463,7 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
         }
         EDMP_HIP_CHECK(hipEventRecord(whole.a, main_stream));
     }
+    auto coff = [&](auto* q) { return q ? q + unet_chain_offset(u, q, r0) : q; };
     int op_index = -1;
     for (const Op& op : u->prog) {
         ++op_index;
@@ -1492,11 +1494,7 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
         if (op.kind == OP_RCB) {
             RcbP p = op.rc;
             p.B = B;
-            p.src1 += r0 * op.rs_src1;
-            if (p.src2) p.src2 += r0 * op.rs_src2;
-            p.dst += r0 * op.rs_dst;
-            if (p.add_res) p.add_res += r0 * op.rs_res;
-            if (p.res_out) p.res_out += r0 * op.rs_resout;
+            p.src1 = coff(p.src1), p.src2 = coff(p.src2), p.dst = coff(p.dst), p.add_res = coff(p.add_res), p.res_out = coff(p.res_out);
             p.add_tb = op.tb_off >= 0 ? trow + op.tb_off : nullptr;
             EDMP_REQUIRE(!(p.add_tb && p.add_res), "fused conv block: a launch adds the time bias (conv1) or the residual (conv2), not both");
             rc = launch_rcb(p, op.rc_L, op.rc_form, s);
@@ -1504,10 +1502,7 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
             LevelP p = op.lv;
             p.B = B;
             const bool out_is_head_input = p.out == u->h_last;
-            p.src1 += r0 * op.rs_src1;
-            if (p.src2) p.src2 += r0 * op.rs_src2;
-            if (p.skip_out) p.skip_out += r0 * op.rs_res;
-            p.out += r0 * op.rs_dst;
+            p.src1 = coff(p.src1), p.src2 = coff(p.src2), p.skip_out = coff(p.skip_out), p.out = coff(p.out);
             p.tb1 = trow + op.lv_tb1;
             p.tb2 = trow + op.lv_tb2;
             if (tail && tail_done && op.lv_variant == 4 && op_index + 1 == (int)u->prog.size() && u->head_cin == 32 && tail->N == u->desc.horizon && tail->C <= 8 && out_is_head_input && u->fuse_tail) {
@@ -1521,21 +1516,17 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
         } else if (op.kind == OP_WRS) {
             RcbP p = op.rc;
             p.B = B;
-            p.src1 += r0 * op.rs_src1;
-            p.dst += r0 * op.rs_dst;
+            p.src1 = coff(p.src1), p.dst = coff(p.dst);
             rc = launch_wrs(p, op.wrs_kind, op.rc_L, s);
         } else if (op.kind == OP_CONV) {
             ConvP p = op.cv;
             p.B = B;
-            p.src1 += r0 * op.rs_src1;
-            if (p.src2) p.src2 += r0 * op.rs_src2;
-            p.dst += r0 * op.rs_dst;
+            p.src1 = coff(p.src1), p.src2 = coff(p.src2), p.dst = coff(p.dst);
             launch_conv(p, s);
         } else {
             GnP g = op.gn;
             g.B = B;
-            g.y += r0 * op.rs_dst;
-            if (g.add_res) g.add_res += r0 * op.rs_res;
+            g.y = coff(g.y), g.add_res = coff(g.add_res);
             g.add_tbias = op.tb_off >= 0 ? trow + op.tb_off : nullptr;
             rc = launch_gn(g, s);
         }
