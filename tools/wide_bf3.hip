@@ -60,7 +60,14 @@ struct Bf3Cfg {
 
 #ifdef BF3_STAMPS
 __device__ long long g_bf3_stamps[8][8];
-#define BF3_STAMP(i) if (blockIdx.x == 0 && lane == 0) g_bf3_stamps[wave][i] = clock64();
+__device__ unsigned long long g_bf3_wall[2] = {~0ull, 0ull};  // earliest workgroup start / latest workgroup end of the launch (100 MHz wall clock)
+#define BF3_STAMP(i)                                                              \
+    if (blockIdx.x == 0 && lane == 0) {                                           \
+        g_bf3_stamps[wave][i] = clock64();                                        \
+        if ((i) == 0 || (i) == 3) g_bf3_stamps[wave][(i) == 0 ? 6 : 7] = (long long)wall_clock64(); \
+    }                                                                             \
+    if ((i) == 0 && threadIdx.x == 0) atomicMin(&g_bf3_wall[0], wall_clock64()); \
+    if ((i) == 3 && threadIdx.x == 0) atomicMax(&g_bf3_wall[1], wall_clock64());
 #else
 #define BF3_STAMP(i)
 #endif
