@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256, (SB <= 2 ? 2 : 1)) void level_kernel(const flo
     const int rq4 = 4 * (lane >> 4);       // first accumulator row of this lane within a tile
 
     EDMP_STAMP(LVSLOT, 0)
+    EDMP_WG_STAMP(0)
     float4 bf[6];  // weight fragments of the next stage's first K group, requested one stage early
     // ---- level input staging.  With a wide input (the up levels: CIN = 128 / 256 concatenated channels, 51 KB per workgroup
     //      that every XCD has to pull from HBM at the same moment) the tile is staged in NCH channel chunks: chunk 0 up
@@ -154,6 +155,11 @@ __global__ __launch_bounds__(256, (SB <= 2 ? 2 : 1)) void level_kernel(const flo
             }
 #pragma unroll
         for (int u = 0; u < NIT; ++u) in_commit(0, u, vin[u]);
+    }
+    if (p.stagger_cycles > 0 && ((blockIdx.x >> p.stagger_bit) & 1)) {
+        // (the input and the first weight fragments are already on their way / in LDS: the wait costs the late workgroup nothing but time)
+        const long long t0 = clock64();
+        while (clock64() - t0 < p.stagger_cycles) __builtin_amdgcn_s_sleep(4);
     }
     __syncthreads();
 
@@ -528,6 +534,7 @@ __global__ __launch_bounds__(256, (SB <= 2 ? 2 : 1)) void level_kernel(const flo
         }
     }
     EDMP_STAMP(LVSLOT, 7)
+    EDMP_WG_STAMP(1)
 #undef EDMP_IC
 }
 

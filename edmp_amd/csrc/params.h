@@ -73,6 +73,10 @@ struct LevelP {
     float* out;       // [B][LOUT][C] (LV_UP_FINAL: the final Conv1dBlock's output at the up-sampled length)
     int B;
     TailP tail;       // LV_UP_FINAL in the device-resident loop: head 1x1 conv + posterior step on the tile still in LDS (tail.h)
+    // phase offset between the two workgroups that share a CU (SB = 2 instances): workgroups whose id has bit `stagger_bit` set
+    // wait `stagger_cycles` shader cycles before their first stage, so that one workgroup's GroupNorm / Mish epilogues (VALU) run
+    // under the other's MFMA phases systematically instead of by chance; 0 = off
+    int stagger_cycles = 0, stagger_bit = 0;
 };
 
 #ifdef EDMP_STAMPS  // phase timing experiment (scratch builds only): one wave of one mid-grid workgroup stamps s_memtime
@@ -86,8 +90,23 @@ extern __device__ unsigned long long g_stamps[8][16];
         g_stamps[k][2 * (i)] = clock64();                                       \
         g_stamps[k][2 * (i) + 1] = wall_clock64();                              \
     }
+// per-workgroup dispatch timeline (tools/levelbench.hip): wall clock at entry / exit and the hardware id (XCC, SE, CU) of every workgroup
+#ifdef EDMP_STAMPS_DEFINE
+__device__ unsigned long long g_wg_times[1024][4];
+#else
+extern __device__ unsigned long long g_wg_times[1024][4];
+#endif
+#define EDMP_WG_STAMP(i)                                                                        \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                \
+        g_wg_times[blockIdx.x][i] = wall_clock64();                                             \
+        if ((i) == 0) {                                                                         \
+            g_wg_times[blockIdx.x][2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); /* HW_REG_XCC_ID */ \
+            g_wg_times[blockIdx.x][3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  /* HW_REG_HW_ID */  \
+        }                                                                                       \
+    }
 #else
 #define EDMP_STAMP(k, i)
+#define EDMP_WG_STAMP(i)
 #endif
 
 }  // namespace edmp

@@ -614,6 +614,29 @@ static int level_sb(int variant) {
     const char* t = (e && strlen(e) == 4) ? e : kDefault;
     return t[variant - 1] == '2' ? 2 : 4;
 }
+// EDMP_LEVEL_STAGGER=<cycles>@<bit>[;<cycles>@<bit> ... for variants 1..4]: phase offset of the co-resident workgroups (LevelP::stagger_*),
+// read when a model is built (A/B runs)
+static void level_stagger(int variant, int* cycles, int* bit) {
+    static const char kDefault[] = "";
+    const char* e = getenv("EDMP_LEVEL_STAGGER");
+    const char* t = e ? e : kDefault;
+    *cycles = 0, *bit = 0;
+    int k = 1;
+    while (*t) {
+        int c = 0, b = 0;
+        if (sscanf(t, "%d@%d", &c, &b) < 1) break;
+        const char* semi = strchr(t, ';');
+        if (!semi) {  // one pair: every variant
+            if (k == 1) *cycles = c, *bit = b;
+            else if (k == variant) *cycles = c, *bit = b;
+            break;
+        }
+        if (k == variant) *cycles = c, *bit = b;
+        t = semi + 1;
+        ++k;
+        if (k == variant && !*t) break;
+    }
+}
 static int launch_level(const LevelP& p, int variant, int sb, hipStream_t s) {
     switch (variant * 10 + sb) {
         case 14: return launch_level_t<LV_DOWN, 32, 50, 4, 8>(p, s);
@@ -1326,6 +1349,7 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
             c.out = u->bufs[o.dst];
             op.lv_variant = o.lv_variant;
             op.lv_sb = level_sb(o.lv_variant);
+            level_stagger(o.lv_variant, &c.stagger_cycles, &c.stagger_bit);
             op.lv_tb1 = o.lv_tb1;
             op.lv_tb2 = o.lv_tb2;
             op.flops_nominal = o.fn;

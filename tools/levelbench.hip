@@ -19,6 +19,9 @@ using namespace edmp;
 #define CINV 128
 #define SLOT 4
 #endif
+#ifndef SBV
+#define SBV 4  // samples per workgroup (2: two co-resident workgroups per CU)
+#endif
 int main() {
     const int B = 1024;
     std::mt19937 g(1);
@@ -38,14 +41,38 @@ int main() {
     p.skip_out = (MODE == LV_DOWN) ? skip : nullptr; p.out = out; p.B = B;
     (void)pp;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 5; ++i) launch_level_t<MODE, CV, LV, 4, CINV>(p, 0);
+    for (int i = 0; i < 5; ++i) launch_level_t<MODE, CV, LV, SBV, CINV>(p, 0);
     hipEventRecord(e0, 0);
-    for (int i = 0; i < 50; ++i) launch_level_t<MODE, CV, LV, 4, CINV>(p, 0);
+    for (int i = 0; i < 50; ++i) launch_level_t<MODE, CV, LV, SBV, CINV>(p, 0);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long st[8][16];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(edmp::g_stamps), sizeof(st));
     printf("%.2f us/launch (in-kernel %.2f us) | zero+load %llu | conv11 %llu | epi11 %llu | conv12 %llu | epi12 %llu | RCB2 %llu | resample %llu | %s\n", ms * 1000 / 50, (st[SLOT][15] - st[SLOT][1]) / 100.0,
            st[SLOT][2] - st[SLOT][0], st[SLOT][4] - st[SLOT][2], st[SLOT][6] - st[SLOT][4], st[SLOT][8] - st[SLOT][6], st[SLOT][10] - st[SLOT][8], st[SLOT][12] - st[SLOT][10], st[SLOT][14] - st[SLOT][12], hipGetErrorString(hipGetLastError()));
+    {   // dispatch timeline of ONE launch (the last of the chain): when every workgroup started / ended, and on which CU
+        const int nwg = (B + SBV - 1) / SBV;
+        static unsigned long long wt[1024][4];
+        hipMemcpyFromSymbol(wt, HIP_SYMBOL(edmp::g_wg_times), sizeof(wt));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int i = 0; i < nwg && i < 1024; ++i) { t0 = wt[i][0] < t0 ? wt[i][0] : t0; t1 = wt[i][1] > t1 ? wt[i][1] : t1; }
+        int hist[64] = {0};
+        double dur = 0, late = 0;
+        std::vector<int> percu(8 * 64, 0);
+        for (int i = 0; i < nwg && i < 1024; ++i) {
+            const double st0 = (wt[i][0] - t0) / 100.0;
+            hist[(int)st0 < 63 ? (int)st0 : 63]++;
+            dur += (wt[i][1] - wt[i][0]) / 100.0;
+            late = st0 > late ? st0 : late;
+            const unsigned xcc = wt[i][2] & 0xf, hw = (unsigned)wt[i][3];
+            const unsigned cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 0x7;
+            percu[xcc * 64 + se * 16 + sh * 8 + (cu & 7)]++;  // (layout of HW_ID is approximate: used only to count distinct slots)
+        }
+        int cus = 0, mx = 0;
+        for (int v : percu) { cus += v > 0; mx = v > mx ? v : mx; }
+        printf("  launch span %.2f us over %d workgroups | mean workgroup duration %.2f us | last start +%.2f us | distinct (xcc, hw id) slots %d, max workgroups on one %d | starts per us:", (t1 - t0) / 100.0, nwg, dur / nwg, late, cus, mx);
+        for (int i = 0; i < 16; ++i) printf(" %d", hist[i]);
+        printf("\n");
+    }
     return 0;
 }
