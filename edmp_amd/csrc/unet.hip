@@ -856,453 +856,423 @@ extern "C" int64_t edmp_unet_param_count(const edmp_unet_desc* desc) {
 // one written under other builder switches, fails to load instead of feeding a kernel the wrong fragment order.
 static const int kPackVersion = 300;
 
-// builds the layer program + device weight image.  packed == nullptr: repack `params` (state-dict order) on the host;
-// otherwise `packed` IS the device image (edmp_unet_read_packed of the same architecture): only the layout is computed
-static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* params, int64_t n_params, int max_batch, const float* packed,
-                      int64_t n_packed, int packed_layout) {
-    ctx->epoch++;
-    EDMP_REQUIRE(desc->n_levels >= 2 && desc->n_levels <= EDMP_MAX_LEVELS, "n_levels out of range");
-    EDMP_REQUIRE(desc->input_dim >= 1 && desc->input_dim <= 8, "input_dim must be in 1..8");
-    EDMP_REQUIRE(desc->time_dim >= 4 && desc->time_dim % 2 == 0, "time_dim must be even");
-    EDMP_REQUIRE(max_batch >= 1, "max_batch must be positive");
-    for (int i = 0; i < desc->n_levels; ++i) EDMP_REQUIRE(desc->dims[i] % 8 == 0 && desc->dims[i] >= 8, "dims must be multiples of 8");
-    RawNet inv = inventory(*desc);
-    static const float no_params = 0.0f;
-    if (packed) {  // layout-only pass: the builder computes offsets from `params` but never reads through it (Packer::dry)
-        params = &no_params;
-        n_params = inv.total;
-    }
-    EDMP_REQUIRE(inv.total == n_params, "parameter blob has %lld floats, architecture needs %lld", (long long)n_params, (long long)inv.total);
-    EDMP_HIP_CHECK(hipSetDevice(ctx->device));
-    if (ctx->unet) {
-        unet_destroy(ctx->unet);
-        ctx->unet = nullptr;
-    }
-    // owned here until the build has succeeded: every early return below (argument checks, failed allocations / copies /
-    // launches) releases the weight image and the activation buffers
-    std::unique_ptr<UNet, void (*)(UNet*)> guard(new UNet(), unet_destroy);
-    UNet* u = guard.get();
-    u->desc = *desc;
-    u->max_batch = max_batch;
-    u->fuse_tail = fuse_tail();
-    const int N = desc->horizon;
-    const int td = desc->time_dim;
-    std::vector<int> dm{desc->input_dim};
-    for (int i = 0; i < desc->n_levels; ++i) dm.push_back(desc->dims[i]);
-    const int nd = desc->n_levels;
-    const int CP0 = 8;  // padded input channels
+// ---- step 1 of a model build: the LAYER PLAN -----------------------------------------------------------------------------
+// An op of the plan: which kernel family, which activation buffers (ids of the pool) and which tensors of the packed weight image
+// (float offsets); resolved to device pointers by resolve_program() once the image and the buffers exist.
+struct POp {
+    OpKind kind;
+    int src1, src2, C1, C2, Lin, Lout, ntaps, stride, pad, transposed, Cout;
+    size_t w, b;
+    int dst;
+    // gn
+    int y, L, C, res;
+    size_t gamma, beta;
+    int tb_off;
+    double fn, fe, fd;  // FLOPs per trajectory: nominal | issued | direct form without padding taps (0: same as fe)
+    int branch;
+    size_t br;  // bias of a residual 1x1 conv folded into an OP_RCB
+    int blk;
+    int res_out;  // OP_RCB: buffer receiving the folded residual 1x1 conv (-1: none)
+    // OP_LVL: offsets of the level's tensors in the packed image, in LevelP order; lv_skip: buffer of the skip output (-1: none)
+    size_t lvo[24];
+    int lv_variant, lv_tb1, lv_tb2, lv_skip;
+    // fused conv+gn (OP_RCB): uses src1/src2/C1/C2/Lin/Cout/w/b/dst + gamma/beta/res/tb_off
+};
 
+// the builder's run-time switches, read ONCE per model build and frozen into its plan (two models built under different settings
+// coexist in one process: A/B runs, the adversarial-weights test)
+struct BuildSwitches {
+    bool fused, side, resfold, level;
+    static BuildSwitches read() {
+        BuildSwitches s;
+        s.fused = getenv("EDMP_NO_FUSED") == nullptr;
+        s.side = getenv("EDMP_SIDE_STREAM") != nullptr;  // measured slower (event sync > overlap gain): opt-in
+        s.resfold = getenv("EDMP_NO_RESFOLD") == nullptr;
+        s.level = s.fused && getenv("EDMP_NO_LEVEL") == nullptr && !s.side;
+        return s;
+    }
+};
+
+// Walks the architecture (temporalunet.py:47-76) once: decides per layer which kernel family runs it, packs its weights into the
+// device image in that family's layout (or only sizes them: Packer::dry, loading a packed image), assigns activation buffers from a
+// recycling pool and records the FLOP counts.  No device work.
+struct LayerPlan {
+    const edmp_unet_desc* desc;
+    const float* params;   // state-dict blob (never read through when pk.dry)
+    RawNet inv;
+    BuildSwitches sw;
+    int N, td, nd, CP0 = 8;  // horizon, time_dim, levels, padded input channels
+    std::vector<int> dm;     // input_dim, dims...
+    // products
     Packer pk;
-    pk.dry = packed != nullptr;
     BufPool pool;
-    // program is first built with buffer ids / weight offsets, resolved to pointers after allocation
-    struct POp {
-        OpKind kind;
-        int src1, src2, C1, C2, Lin, Lout, ntaps, stride, pad, transposed, Cout;
-        size_t w, b;
-        int dst;
-        // gn
-        int y, L, C, res;
-        size_t gamma, beta;
-        int tb_off;
-        double fn, fe, fd;  // FLOPs per trajectory: nominal | issued | direct form without padding taps (0: same as fe)
-        int branch;
-        size_t br;  // bias of a residual 1x1 conv folded into an OP_RCB
-        int blk;
-        int res_out;  // OP_RCB: buffer receiving the folded residual 1x1 conv (-1: none)
-        // OP_LVL: offsets of the level's tensors in the packed image, in LevelP order; lv_skip: buffer of the skip output (-1: none)
-        size_t lvo[24];
-        int lv_variant, lv_tb1, lv_tb2, lv_skip;
-        // fused conv+gn (OP_RCB): uses src1/src2/C1/C2/Lin/Cout/w/b/dst + gamma/beta/res/tb_off
-    };
     std::vector<POp> pops;
-    const bool use_fused = getenv("EDMP_NO_FUSED") == nullptr;
-    const bool use_side = getenv("EDMP_SIDE_STREAM") != nullptr;  // measured slower (event sync > overlap gain): opt-in
-    // concatenated time-MLP weights
-    std::vector<float> tw_all, tb_all;
-    int tb_cursor = 0;
-    auto append = [&](std::vector<float>& v, const float* src, size_t n) {  // layout-only pass: sizes, no reads
-        if (pk.dry) v.resize(v.size() + n, 0.0f);
-        else v.insert(v.end(), src, src + n);
-    };
-
-    auto valid_pairs = [](int Lin, int Lout, int k, int stride, int pad, bool tr) {
-        long cnt = 0;
-        for (int lo = 0; lo < Lout; ++lo)
-            for (int t = 0; t < k; ++t) {
-                if (!tr) {
-                    int li = lo * stride + t - pad;
-                    if (li >= 0 && li < Lin) ++cnt;
-                } else {
-                    int num = lo + pad - t;
-                    if (num >= 0 && num % stride == 0 && num / stride < Lin) ++cnt;
-                }
-            }
-        return cnt;
-    };
-    auto emit_conv = [&](TH a, const TH* a2, int cin_true, size_t w, size_t b, int Cout, int k, int stride, int pad, bool tr, int Lout) {
-        POp o{};
-        o.kind = OP_CONV;
-        o.src1 = a.buf;
-        o.C1 = a.C;
-        o.src2 = a2 ? a2->buf : -1;
-        o.C2 = a2 ? a2->C : 0;
-        o.Lin = a.L;
-        o.Lout = Lout;
-        o.ntaps = k;
-        o.stride = stride;
-        o.pad = pad;
-        o.transposed = tr;
-        o.Cout = Cout;
-        o.w = w;
-        o.b = b;
-        o.dst = pool.get();
-        // nominal FLOPs: what torch executes: conv 2*Lout*Cout*Cin*k ; convT 2*Lin*Cin*Cout*k (uncropped)
-        o.fn = tr ? 2.0 * a.L * cin_true * Cout * k : 2.0 * Lout * Cout * (double)cin_true * k;
-        o.fe = 2.0 * (double)valid_pairs(a.L, Lout, k, stride, pad, tr) * Cout * (double)(o.C1 + o.C2);
-        pops.push_back(o);
-        return TH{o.dst, Cout, Lout};
-    };
-    auto emit_wrs = [&](TH a, size_t w, size_t b, int Cout, int kind, int k, int Lout) {
-        POp o{};
-        o.kind = OP_WRS;
-        o.src1 = a.buf;
-        o.C1 = a.C;
-        o.src2 = -1;
-        o.C2 = 0;
-        o.Lin = a.L;
-        o.Lout = Lout;
-        o.ntaps = k;
-        o.transposed = (kind == WK_UP);
-        o.Cout = Cout;
-        o.w = w;
-        o.b = b;
-        o.dst = pool.get();
-        o.res_out = -1;
-        o.blk = kind;
-        const bool tr = kind == WK_UP;
-        o.fn = tr ? 2.0 * a.L * (double)a.C * Cout * k : 2.0 * Lout * Cout * (double)a.C * k;
-        o.fe = 2.0 * (double)valid_pairs(a.L, Lout, k, 2, 1, tr) * Cout * (double)a.C;
-        pops.push_back(o);
-        return TH{o.dst, Cout, Lout};
-    };
-    auto emit_gn = [&](TH y, size_t gamma, size_t beta, int res_buf, int tb_off) {
-        POp o{};
-        o.kind = OP_GN;
-        o.y = y.buf;
-        o.L = y.L;
-        o.C = y.C;
-        o.gamma = gamma;
-        o.beta = beta;
-        o.res = res_buf;
-        o.tb_off = tb_off;
-        pops.push_back(o);
-    };
-    auto emit_fused = [&](TH a, const TH* a2, int cin_true, int cout, size_t w, size_t b, size_t gamma, size_t beta, int res_buf, int tbo) {
-        POp o{};
-        o.kind = OP_RCB;
-        o.src1 = a.buf;
-        o.C1 = a.C;
-        o.src2 = a2 ? a2->buf : -1;
-        o.C2 = a2 ? a2->C : 0;
-        o.Lin = a.L;
-        o.Lout = a.L;
-        o.ntaps = 5;
-        o.Cout = cout;
-        o.w = w;
-        o.b = b;
-        o.gamma = gamma;
-        o.beta = beta;
-        o.res = res_buf;
-        o.tb_off = tbo;
-        o.res_out = -1;
-        o.dst = pool.get();
-        o.fn = 2.0 * a.L * cout * (double)cin_true * 5;
-        // executed = issued MFMA work: the L = 2 Karatsuba form runs 3 matrix products where the direct form runs 4
-        const bool k2 = a.L == 2 && cout / 8 == 64 && karatsuba_l2() && rcb_supported(cout, a.L, o.C1, o.C2);
-        const bool k4 = a.L == 4 && cout / 8 >= 32 && karatsuba_l4() && rcb_supported(cout, a.L, o.C1, o.C2);
-        o.fe = 2.0 * (k2 ? 3.0 : k4 ? 9.0 : (double)valid_pairs(a.L, a.L, 5, 1, 2, false)) * cout * (double)(o.C1 + o.C2);
-        o.fd = 2.0 * (double)valid_pairs(a.L, a.L, 5, 1, 2, false) * cout * (double)(o.C1 + o.C2);
-        pops.push_back(o);
-        return TH{o.dst, cout, a.L};
-    };
-    int rcb_idx = 0;
-    auto emit_rcb = [&](TH x, const TH* x2) -> TH {
-        const RawRCB& r = inv.rcbs[rcb_idx++];
-        const int cin_store = x.C + (x2 ? x2->C : 0);
-        // conv1 (a residual 1x1 conv folded into the wide fused kernel is packed right behind it, as tap index 5)
-        const bool wide = use_fused && rcb_supported(r.cout, x.L, x.C, x2 ? x2->C : 0);
-        const bool fold_res = wide && r.has_res && getenv("EDMP_NO_RESFOLD") == nullptr && !use_side;
-        // the position-tile kernel reads its weights as an MFMA fragment stream (wide.hip); the generic conv as [tap][Cout][Cin]
-        size_t w1 = wide ? pk.conv_frag(params + r.cb[0].w.off, fold_res ? params + r.rw.off : nullptr, r.cout, r.cin, cin_store, x.L)
-                         : pk.conv(params + r.cb[0].w.off, r.cout, r.cin, 5, cin_store);
-        size_t b1 = pk.vec(params + r.cb[0].b.off, r.cout);
-        size_t g1 = pk.vec(params + r.cb[0].gw.off, r.cout), be1 = pk.vec(params + r.cb[0].gb.off, r.cout);
-        size_t w2 = wide ? pk.conv_frag(params + r.cb[1].w.off, nullptr, r.cout, r.cout, r.cout, x.L) : pk.conv(params + r.cb[1].w.off, r.cout, r.cout, 5, r.cout);
-        size_t b2 = pk.vec(params + r.cb[1].b.off, r.cout);
-        size_t g2 = pk.vec(params + r.cb[1].gw.off, r.cout), be2 = pk.vec(params + r.cb[1].gb.off, r.cout);
-        int tb_off = tb_cursor;
-        tb_cursor += r.cout;
-        append(tw_all, params + r.tw.off, (size_t)r.cout * td);
-        append(tb_all, params + r.tb.off, r.cout);
-        if (wide) {
-            TH h = emit_fused(x, x2, r.cin, r.cout, w1, b1, g1, be1, -1, tb_off);
-            int res_buf;
-            int rr_buf = -1;
-            if (fold_res) {
-                POp& c1 = pops.back();
-                c1.res_out = pool.get();
-                c1.br = pk.vec(params + r.rb.off, r.cout);
-                c1.fn += 2.0 * x.L * r.cout * (double)r.cin;
-                c1.fe += 2.0 * x.L * r.cout * (double)cin_store;
-                c1.fd += 2.0 * x.L * r.cout * (double)cin_store;
-                rr_buf = c1.res_out;
-                res_buf = c1.res_out;
-            } else if (r.has_res) {
-                // the residual 1x1 conv only depends on the block input: it runs concurrently with conv1 on the side stream
-                size_t wr = pk.conv(params + r.rw.off, r.cout, r.cin, 1, cin_store);
-                size_t br = pk.vec(params + r.rb.off, r.cout);
-                if (use_side) pops.back().branch = 1;
-                TH rr = emit_conv(x, x2, r.cin, wr, br, r.cout, 1, 1, 0, false, x.L);
-                if (use_side) pops.back().branch = 2;
-                rr_buf = rr.buf;
-                res_buf = rr.buf;
-            } else {
-                res_buf = x2 ? -2 : x.buf;
-            }
-            TH out = emit_fused(h, nullptr, r.cout, r.cout, w2, b2, g2, be2, res_buf, -1);
-            if (use_side && r.has_res) pops.back().branch = 3;
-            pool.put(h.buf);
-            if (rr_buf >= 0) pool.put(rr_buf);
-            return out;
-        }
-        TH y1 = emit_conv(x, x2, r.cin, w1, b1, r.cout, 5, 1, 2, false, x.L);
-        emit_gn(y1, g1, be1, -1, tb_off);
-        TH y2 = emit_conv(y1, nullptr, r.cout, w2, b2, r.cout, 5, 1, 2, false, x.L);
-        pool.put(y1.buf);
-        if (r.has_res) {
-            size_t wr = pk.conv(params + r.rw.off, r.cout, r.cin, 1, cin_store);
-            size_t br = pk.vec(params + r.rb.off, r.cout);
-            TH rr = emit_conv(x, x2, r.cin, wr, br, r.cout, 1, 1, 0, false, x.L);
-            emit_gn(y2, g2, be2, rr.buf, -1);
-            pool.put(rr.buf);
-        } else {
-            emit_gn(y2, g2, be2, x2 ? -2 : x.buf, -1);  // identity residual (blocks.py:151-152); -2 = unsupported concat
-        }
-        return y2;
-    };
-
-    // a whole level in one launch (level.hip): RCB, RCB, resampling conv (+ the final Conv1dBlock); consumes two entries
-    // of inv.rcbs like two emit_rcb calls would, in the same order (so the time-bias row keeps its layout)
-    auto emit_level = [&](int mode, int variant, TH xin, const TH* x2, const RawT& rs_w, const RawT& rs_b, bool want_skip, TH* skip_th) -> TH {
-        const RawRCB& r1 = inv.rcbs[rcb_idx++];
-        const RawRCB& r2 = inv.rcbs[rcb_idx++];
-        const int Cc = r1.cout, Ll = xin.L, KX = level_kx(variant);
-        const int cin_store = xin.C + (x2 ? x2->C : 0);
-        POp o{};
-        o.kind = OP_LVL;
-        o.lv_variant = variant;
-        o.src1 = xin.buf;
-        o.C1 = xin.C;
-        o.src2 = x2 ? x2->buf : -1;
-        o.C2 = x2 ? x2->C : 0;
-        o.Lin = Ll;
-        o.Cout = Cc;
-        size_t* q = o.lvo;
-        // LevelP order: w11 w12 w21 w22 wrs wfin | b11 g11 be11 rb1 | b12 g12 be12 | b21 g21 be21 | b22 g22 be22 | brs | bfin gfin befin
-        q[0] = pk.conv_frag(params + r1.cb[0].w.off, params + r1.rw.off, Cc, r1.cin, KX, Ll);
-        q[1] = pk.conv_frag(params + r1.cb[1].w.off, nullptr, Cc, Cc, Cc, Ll);
-        q[2] = pk.conv_frag(params + r2.cb[0].w.off, nullptr, Cc, Cc, Cc, Ll);
-        q[3] = pk.conv_frag(params + r2.cb[1].w.off, nullptr, Cc, Cc, Cc, Ll);
-        q[4] = pk.resample_frag(params + rs_w.off, Cc, Cc, mode == LV_DOWN ? 3 : 4, mode != LV_DOWN);
-        q[5] = (mode == LV_UP_FINAL) ? pk.conv_frag(params + inv.final_cb.w.off, nullptr, Cc, Cc, Cc, 50) : 0;
-        q[6] = pk.vec(params + r1.cb[0].b.off, Cc), q[7] = pk.vec(params + r1.cb[0].gw.off, Cc), q[8] = pk.vec(params + r1.cb[0].gb.off, Cc);
-        q[9] = pk.vec(params + r1.rb.off, Cc);
-        q[10] = pk.vec(params + r1.cb[1].b.off, Cc), q[11] = pk.vec(params + r1.cb[1].gw.off, Cc), q[12] = pk.vec(params + r1.cb[1].gb.off, Cc);
-        q[13] = pk.vec(params + r2.cb[0].b.off, Cc), q[14] = pk.vec(params + r2.cb[0].gw.off, Cc), q[15] = pk.vec(params + r2.cb[0].gb.off, Cc);
-        q[16] = pk.vec(params + r2.cb[1].b.off, Cc), q[17] = pk.vec(params + r2.cb[1].gw.off, Cc), q[18] = pk.vec(params + r2.cb[1].gb.off, Cc);
-        q[19] = pk.vec(params + rs_b.off, Cc);
-        if (mode == LV_UP_FINAL) {
-            q[20] = pk.vec(params + inv.final_cb.b.off, Cc), q[21] = pk.vec(params + inv.final_cb.gw.off, Cc), q[22] = pk.vec(params + inv.final_cb.gb.off, Cc);
-        }
-        for (const RawRCB* r : {&r1, &r2}) {  // time-bias table columns, block order
-            (r == &r1 ? o.lv_tb1 : o.lv_tb2) = tb_cursor;
-            tb_cursor += Cc;
-            append(tw_all, params + r->tw.off, (size_t)Cc * td);
-            append(tb_all, params + r->tb.off, Cc);
-        }
-        o.lv_skip = -1;
-        if (want_skip) {
-            o.lv_skip = pool.get();
-            *skip_th = TH{o.lv_skip, Cc, Ll};
-        }
-        int Lout = (mode == LV_DOWN) ? (Ll - 1) / 2 + 1 : 2 * Ll;
-        if (mode != LV_DOWN && (Lout == 8 || Lout == 14 || Lout == 26)) Lout -= 1;
-        o.Lout = Lout;
-        o.dst = pool.get();
-        const double vp = (double)valid_pairs(Ll, Ll, 5, 1, 2, false);
-        const int k = mode == LV_DOWN ? 3 : 4;
-        o.fn = 2.0 * Ll * Cc * 5.0 * ((double)r1.cin + 3.0 * Cc) + 2.0 * Ll * Cc * (double)r1.cin +
-               (mode == LV_DOWN ? 2.0 * Lout * Cc * (double)Cc * k : 2.0 * Ll * (double)Cc * Cc * k) + (mode == LV_UP_FINAL ? 2.0 * Lout * Cc * (double)Cc * 5 : 0.0);
-        o.fe = 2.0 * vp * Cc * ((double)cin_store + 3.0 * Cc) + 2.0 * Ll * Cc * (double)cin_store +
-               2.0 * (double)valid_pairs(Ll, Lout, k, 2, 1, mode != LV_DOWN) * Cc * (double)Cc +
-               (mode == LV_UP_FINAL ? 2.0 * (double)valid_pairs(Lout, Lout, 5, 1, 2, false) * Cc * (double)Cc : 0.0);
-        pops.push_back(o);
-        return TH{o.dst, Cc, Lout};
-    };
-    const bool use_level = use_fused && getenv("EDMP_NO_LEVEL") == nullptr && !use_side;
-
-    TH x{pool.get(), CP0, N};
-    const int x_in_buf = x.buf;
-    pool.pin(x_in_buf);  // written by the sampler kernels between forwards: never recycled as an activation
-    std::vector<TH> skips;
+    std::vector<float> tw_all, tb_all;  // concatenated time-MLP weights of the residual blocks
+    int tb_cursor = 0, rcb_idx = 0;
+    int x_in_buf = -1, head_buf = -1;
     bool final_fused = false;
     struct TapRec { int which; int buf, C, L; };
     std::vector<TapRec> tapr;
-    for (int i = 0; i < nd; ++i) {
-        if (const int lvv = (use_level && i != nd - 1) ? level_variant(LV_DOWN, dm[i + 1], x.L, x.C, 0) : 0) {
-            // the skip of level 0 is never consumed (5 up-samplers for 6 skips, temporalunet.py:31-32,66-67): not even written
-            TH sk{-1, dm[i + 1], x.L};
-            TH xo = emit_level(LV_DOWN, lvv, x, nullptr, inv.down_w[i], inv.down_b[i], i > 0, &sk);
-            pool.put(x.buf);
-            skips.push_back(sk);
-            x = xo;
-            tapr.push_back({i, x.buf, x.C, x.L});
-            pool.pin(x.buf);
-            continue;
-        }
-        TH a = emit_rcb(x, nullptr);
-        pool.put(x.buf);  // the block input is dead once both consumers (conv1, residual) are emitted
-        TH b = emit_rcb(a, nullptr);
-        pool.put(a.buf);
-        skips.push_back(b);
-        if (i != nd - 1) {
-            int Lout = (b.L - 1) / 2 + 1;
-            if (use_fused && wrs_supported(dm[i + 1], b.C, b.L, false)) {
-                size_t w = pk.resample_frag(params + inv.down_w[i].off, dm[i + 1], dm[i + 1], 3, false);
-                size_t bb = pk.vec(params + inv.down_b[i].off, dm[i + 1]);
-                x = emit_wrs(b, w, bb, dm[i + 1], WK_DOWN, 3, Lout);
-            } else {
-                size_t w = pk.conv(params + inv.down_w[i].off, dm[i + 1], dm[i + 1], 3, dm[i + 1]);
-                size_t bb = pk.vec(params + inv.down_b[i].off, dm[i + 1]);
-                x = emit_conv(b, nullptr, dm[i + 1], w, bb, dm[i + 1], 3, 2, 1, false, Lout);
-            }
-        } else {
-            x = b;
-        }
-        tapr.push_back({i, x.buf, x.C, x.L});
-        pool.pin(x.buf);
+    size_t hw = 0, hb = 0, o_t1w = 0, o_t1b = 0, o_t3w = 0, o_t3b = 0, o_tw = 0, o_tb = 0;
+    double head_flops = 0;
+
+    LayerPlan(const edmp_unet_desc* d, const float* blob, bool layout_only) : desc(d), params(blob), inv(inventory(*d)), sw(BuildSwitches::read()) {
+        N = d->horizon, td = d->time_dim, nd = d->n_levels;
+        dm.push_back(d->input_dim);
+        for (int i = 0; i < d->n_levels; ++i) dm.push_back(d->dims[i]);
+        pk.dry = layout_only;
     }
-    {
-        // middle: input is skips.back() (same buffer, must stay alive for the up path)
-        TH a = emit_rcb(x, nullptr);
-        TH b = emit_rcb(a, nullptr);
-        pool.put(a.buf);
-        x = b;
-        tapr.push_back({100, x.buf, x.C, x.L});
-        pool.pin(x.buf);
-    }
-    for (int j = 0, i = nd; i > 1; --i, ++j) {
-        TH sk = skips.back();
-        skips.pop_back();
-        EDMP_REQUIRE(sk.L == x.L && sk.C == x.C, "skip/upsample shape mismatch at up level %d (L %d vs %d)", j, sk.L, x.L);
-        EDMP_REQUIRE(sk.buf >= 0, "up level %d consumes a skip tensor that the fused down level did not write", j);
-        {
-            const bool last = (i == 2);
-            const int mode = (last && dm[1] == dm[i - 1] && 2 * x.L == N) ? LV_UP_FINAL : LV_UP;
-            if (const int lvv = use_level ? level_variant(mode, dm[i - 1], x.L, x.C, sk.C) : 0) {
-                TH xo = emit_level(mode, lvv, x, &sk, inv.up_w[j], inv.up_b[j], false, nullptr);
-                pool.put(x.buf);
-                pool.put(sk.buf);
-                x = xo;
-                if (mode == LV_UP_FINAL) {
-                    final_fused = true;  // the level kernel already applied final_conv.0
-                } else {
-                    tapr.push_back({200 + j, x.buf, x.C, x.L});
-                    pool.pin(x.buf);
+
+
+        void append(std::vector<float>& v, const float* src, size_t n) {  // layout-only pass: sizes, no reads
+            if (pk.dry) v.resize(v.size() + n, 0.0f);
+            else v.insert(v.end(), src, src + n);
+        }
+
+        static long valid_pairs(int Lin, int Lout, int k, int stride, int pad, bool tr) {
+            long cnt = 0;
+            for (int lo = 0; lo < Lout; ++lo)
+                for (int t = 0; t < k; ++t) {
+                    if (!tr) {
+                        int li = lo * stride + t - pad;
+                        if (li >= 0 && li < Lin) ++cnt;
+                    } else {
+                        int num = lo + pad - t;
+                        if (num >= 0 && num % stride == 0 && num / stride < Lin) ++cnt;
+                    }
                 }
+            return cnt;
+        }
+        TH emit_conv(TH a, const TH* a2, int cin_true, size_t w, size_t b, int Cout, int k, int stride, int pad, bool tr, int Lout) {
+            POp o{};
+            o.kind = OP_CONV;
+            o.src1 = a.buf;
+            o.C1 = a.C;
+            o.src2 = a2 ? a2->buf : -1;
+            o.C2 = a2 ? a2->C : 0;
+            o.Lin = a.L;
+            o.Lout = Lout;
+            o.ntaps = k;
+            o.stride = stride;
+            o.pad = pad;
+            o.transposed = tr;
+            o.Cout = Cout;
+            o.w = w;
+            o.b = b;
+            o.dst = pool.get();
+            // nominal FLOPs: what torch executes: conv 2*Lout*Cout*Cin*k ; convT 2*Lin*Cin*Cout*k (uncropped)
+            o.fn = tr ? 2.0 * a.L * cin_true * Cout * k : 2.0 * Lout * Cout * (double)cin_true * k;
+            o.fe = 2.0 * (double)valid_pairs(a.L, Lout, k, stride, pad, tr) * Cout * (double)(o.C1 + o.C2);
+            pops.push_back(o);
+            return TH{o.dst, Cout, Lout};
+        }
+        TH emit_wrs(TH a, size_t w, size_t b, int Cout, int kind, int k, int Lout) {
+            POp o{};
+            o.kind = OP_WRS;
+            o.src1 = a.buf;
+            o.C1 = a.C;
+            o.src2 = -1;
+            o.C2 = 0;
+            o.Lin = a.L;
+            o.Lout = Lout;
+            o.ntaps = k;
+            o.transposed = (kind == WK_UP);
+            o.Cout = Cout;
+            o.w = w;
+            o.b = b;
+            o.dst = pool.get();
+            o.res_out = -1;
+            o.blk = kind;
+            const bool tr = kind == WK_UP;
+            o.fn = tr ? 2.0 * a.L * (double)a.C * Cout * k : 2.0 * Lout * Cout * (double)a.C * k;
+            o.fe = 2.0 * (double)valid_pairs(a.L, Lout, k, 2, 1, tr) * Cout * (double)a.C;
+            pops.push_back(o);
+            return TH{o.dst, Cout, Lout};
+        }
+        void emit_gn(TH y, size_t gamma, size_t beta, int res_buf, int tb_off) {
+            POp o{};
+            o.kind = OP_GN;
+            o.y = y.buf;
+            o.L = y.L;
+            o.C = y.C;
+            o.gamma = gamma;
+            o.beta = beta;
+            o.res = res_buf;
+            o.tb_off = tb_off;
+            pops.push_back(o);
+        }
+        TH emit_fused(TH a, const TH* a2, int cin_true, int cout, size_t w, size_t b, size_t gamma, size_t beta, int res_buf, int tbo) {
+            POp o{};
+            o.kind = OP_RCB;
+            o.src1 = a.buf;
+            o.C1 = a.C;
+            o.src2 = a2 ? a2->buf : -1;
+            o.C2 = a2 ? a2->C : 0;
+            o.Lin = a.L;
+            o.Lout = a.L;
+            o.ntaps = 5;
+            o.Cout = cout;
+            o.w = w;
+            o.b = b;
+            o.gamma = gamma;
+            o.beta = beta;
+            o.res = res_buf;
+            o.tb_off = tbo;
+            o.res_out = -1;
+            o.dst = pool.get();
+            o.fn = 2.0 * a.L * cout * (double)cin_true * 5;
+            // executed = issued MFMA work: the L = 2 Karatsuba form runs 3 matrix products where the direct form runs 4
+            const bool k2 = a.L == 2 && cout / 8 == 64 && karatsuba_l2() && rcb_supported(cout, a.L, o.C1, o.C2);
+            const bool k4 = a.L == 4 && cout / 8 >= 32 && karatsuba_l4() && rcb_supported(cout, a.L, o.C1, o.C2);
+            o.fe = 2.0 * (k2 ? 3.0 : k4 ? 9.0 : (double)valid_pairs(a.L, a.L, 5, 1, 2, false)) * cout * (double)(o.C1 + o.C2);
+            o.fd = 2.0 * (double)valid_pairs(a.L, a.L, 5, 1, 2, false) * cout * (double)(o.C1 + o.C2);
+            pops.push_back(o);
+            return TH{o.dst, cout, a.L};
+        }
+        TH emit_rcb(TH x, const TH* x2) {
+            const RawRCB& r = inv.rcbs[rcb_idx++];
+            const int cin_store = x.C + (x2 ? x2->C : 0);
+            // conv1 (a residual 1x1 conv folded into the wide fused kernel is packed right behind it, as tap index 5)
+            const bool wide = sw.fused && rcb_supported(r.cout, x.L, x.C, x2 ? x2->C : 0);
+            const bool fold_res = wide && r.has_res && sw.resfold && !sw.side;
+            // the position-tile kernel reads its weights as an MFMA fragment stream (wide.hip); the generic conv as [tap][Cout][Cin]
+            size_t w1 = wide ? pk.conv_frag(params + r.cb[0].w.off, fold_res ? params + r.rw.off : nullptr, r.cout, r.cin, cin_store, x.L)
+                             : pk.conv(params + r.cb[0].w.off, r.cout, r.cin, 5, cin_store);
+            size_t b1 = pk.vec(params + r.cb[0].b.off, r.cout);
+            size_t g1 = pk.vec(params + r.cb[0].gw.off, r.cout), be1 = pk.vec(params + r.cb[0].gb.off, r.cout);
+            size_t w2 = wide ? pk.conv_frag(params + r.cb[1].w.off, nullptr, r.cout, r.cout, r.cout, x.L) : pk.conv(params + r.cb[1].w.off, r.cout, r.cout, 5, r.cout);
+            size_t b2 = pk.vec(params + r.cb[1].b.off, r.cout);
+            size_t g2 = pk.vec(params + r.cb[1].gw.off, r.cout), be2 = pk.vec(params + r.cb[1].gb.off, r.cout);
+            int tb_off = tb_cursor;
+            tb_cursor += r.cout;
+            append(tw_all, params + r.tw.off, (size_t)r.cout * td);
+            append(tb_all, params + r.tb.off, r.cout);
+            if (wide) {
+                TH h = emit_fused(x, x2, r.cin, r.cout, w1, b1, g1, be1, -1, tb_off);
+                int res_buf;
+                int rr_buf = -1;
+                if (fold_res) {
+                    POp& c1 = pops.back();
+                    c1.res_out = pool.get();
+                    c1.br = pk.vec(params + r.rb.off, r.cout);
+                    c1.fn += 2.0 * x.L * r.cout * (double)r.cin;
+                    c1.fe += 2.0 * x.L * r.cout * (double)cin_store;
+                    c1.fd += 2.0 * x.L * r.cout * (double)cin_store;
+                    rr_buf = c1.res_out;
+                    res_buf = c1.res_out;
+                } else if (r.has_res) {
+                    // the residual 1x1 conv only depends on the block input: it runs concurrently with conv1 on the side stream
+                    size_t wr = pk.conv(params + r.rw.off, r.cout, r.cin, 1, cin_store);
+                    size_t br = pk.vec(params + r.rb.off, r.cout);
+                    if (sw.side) pops.back().branch = 1;
+                    TH rr = emit_conv(x, x2, r.cin, wr, br, r.cout, 1, 1, 0, false, x.L);
+                    if (sw.side) pops.back().branch = 2;
+                    rr_buf = rr.buf;
+                    res_buf = rr.buf;
+                } else {
+                    res_buf = x2 ? -2 : x.buf;
+                }
+                TH out = emit_fused(h, nullptr, r.cout, r.cout, w2, b2, g2, be2, res_buf, -1);
+                if (sw.side && r.has_res) pops.back().branch = 3;
+                pool.put(h.buf);
+                if (rr_buf >= 0) pool.put(rr_buf);
+                return out;
+            }
+            TH y1 = emit_conv(x, x2, r.cin, w1, b1, r.cout, 5, 1, 2, false, x.L);
+            emit_gn(y1, g1, be1, -1, tb_off);
+            TH y2 = emit_conv(y1, nullptr, r.cout, w2, b2, r.cout, 5, 1, 2, false, x.L);
+            pool.put(y1.buf);
+            if (r.has_res) {
+                size_t wr = pk.conv(params + r.rw.off, r.cout, r.cin, 1, cin_store);
+                size_t br = pk.vec(params + r.rb.off, r.cout);
+                TH rr = emit_conv(x, x2, r.cin, wr, br, r.cout, 1, 1, 0, false, x.L);
+                emit_gn(y2, g2, be2, rr.buf, -1);
+                pool.put(rr.buf);
+            } else {
+                emit_gn(y2, g2, be2, x2 ? -2 : x.buf, -1);  // identity residual (blocks.py:151-152); -2 = unsupported concat
+            }
+            return y2;
+        }
+
+        // a whole level in one launch (level.hip): RCB, RCB, resampling conv (+ the final Conv1dBlock); consumes two entries
+        // of inv.rcbs like two emit_rcb calls would, in the same order (so the time-bias row keeps its layout)
+        TH emit_level(int mode, int variant, TH xin, const TH* x2, const RawT& rs_w, const RawT& rs_b, bool want_skip, TH* skip_th) {
+            const RawRCB& r1 = inv.rcbs[rcb_idx++];
+            const RawRCB& r2 = inv.rcbs[rcb_idx++];
+            const int Cc = r1.cout, Ll = xin.L, KX = level_kx(variant);
+            const int cin_store = xin.C + (x2 ? x2->C : 0);
+            POp o{};
+            o.kind = OP_LVL;
+            o.lv_variant = variant;
+            o.src1 = xin.buf;
+            o.C1 = xin.C;
+            o.src2 = x2 ? x2->buf : -1;
+            o.C2 = x2 ? x2->C : 0;
+            o.Lin = Ll;
+            o.Cout = Cc;
+            size_t* q = o.lvo;
+            // LevelP order: w11 w12 w21 w22 wrs wfin | b11 g11 be11 rb1 | b12 g12 be12 | b21 g21 be21 | b22 g22 be22 | brs | bfin gfin befin
+            q[0] = pk.conv_frag(params + r1.cb[0].w.off, params + r1.rw.off, Cc, r1.cin, KX, Ll);
+            q[1] = pk.conv_frag(params + r1.cb[1].w.off, nullptr, Cc, Cc, Cc, Ll);
+            q[2] = pk.conv_frag(params + r2.cb[0].w.off, nullptr, Cc, Cc, Cc, Ll);
+            q[3] = pk.conv_frag(params + r2.cb[1].w.off, nullptr, Cc, Cc, Cc, Ll);
+            q[4] = pk.resample_frag(params + rs_w.off, Cc, Cc, mode == LV_DOWN ? 3 : 4, mode != LV_DOWN);
+            q[5] = (mode == LV_UP_FINAL) ? pk.conv_frag(params + inv.final_cb.w.off, nullptr, Cc, Cc, Cc, 50) : 0;
+            q[6] = pk.vec(params + r1.cb[0].b.off, Cc), q[7] = pk.vec(params + r1.cb[0].gw.off, Cc), q[8] = pk.vec(params + r1.cb[0].gb.off, Cc);
+            q[9] = pk.vec(params + r1.rb.off, Cc);
+            q[10] = pk.vec(params + r1.cb[1].b.off, Cc), q[11] = pk.vec(params + r1.cb[1].gw.off, Cc), q[12] = pk.vec(params + r1.cb[1].gb.off, Cc);
+            q[13] = pk.vec(params + r2.cb[0].b.off, Cc), q[14] = pk.vec(params + r2.cb[0].gw.off, Cc), q[15] = pk.vec(params + r2.cb[0].gb.off, Cc);
+            q[16] = pk.vec(params + r2.cb[1].b.off, Cc), q[17] = pk.vec(params + r2.cb[1].gw.off, Cc), q[18] = pk.vec(params + r2.cb[1].gb.off, Cc);
+            q[19] = pk.vec(params + rs_b.off, Cc);
+            if (mode == LV_UP_FINAL) {
+                q[20] = pk.vec(params + inv.final_cb.b.off, Cc), q[21] = pk.vec(params + inv.final_cb.gw.off, Cc), q[22] = pk.vec(params + inv.final_cb.gb.off, Cc);
+            }
+            for (const RawRCB* r : {&r1, &r2}) {  // time-bias table columns, block order
+                (r == &r1 ? o.lv_tb1 : o.lv_tb2) = tb_cursor;
+                tb_cursor += Cc;
+                append(tw_all, params + r->tw.off, (size_t)Cc * td);
+                append(tb_all, params + r->tb.off, Cc);
+            }
+            o.lv_skip = -1;
+            if (want_skip) {
+                o.lv_skip = pool.get();
+                *skip_th = TH{o.lv_skip, Cc, Ll};
+            }
+            int Lout = (mode == LV_DOWN) ? (Ll - 1) / 2 + 1 : 2 * Ll;
+            if (mode != LV_DOWN && (Lout == 8 || Lout == 14 || Lout == 26)) Lout -= 1;
+            o.Lout = Lout;
+            o.dst = pool.get();
+            const double vp = (double)valid_pairs(Ll, Ll, 5, 1, 2, false);
+            const int k = mode == LV_DOWN ? 3 : 4;
+            o.fn = 2.0 * Ll * Cc * 5.0 * ((double)r1.cin + 3.0 * Cc) + 2.0 * Ll * Cc * (double)r1.cin +
+                   (mode == LV_DOWN ? 2.0 * Lout * Cc * (double)Cc * k : 2.0 * Ll * (double)Cc * Cc * k) + (mode == LV_UP_FINAL ? 2.0 * Lout * Cc * (double)Cc * 5 : 0.0);
+            o.fe = 2.0 * vp * Cc * ((double)cin_store + 3.0 * Cc) + 2.0 * Ll * Cc * (double)cin_store +
+                   2.0 * (double)valid_pairs(Ll, Lout, k, 2, 1, mode != LV_DOWN) * Cc * (double)Cc +
+                   (mode == LV_UP_FINAL ? 2.0 * (double)valid_pairs(Lout, Lout, 5, 1, 2, false) * Cc * (double)Cc : 0.0);
+            pops.push_back(o);
+            return TH{o.dst, Cc, Lout};
+        }
+
+    // the walk itself: down path, middle, up path, final block + head, time-embedding tensors
+    int plan() {
+
+        TH x{pool.get(), CP0, N};
+        x_in_buf = x.buf;
+        pool.pin(x_in_buf);  // written by the sampler kernels between forwards: never recycled as an activation
+        std::vector<TH> skips;
+        for (int i = 0; i < nd; ++i) {
+            if (const int lvv = (sw.level && i != nd - 1) ? level_variant(LV_DOWN, dm[i + 1], x.L, x.C, 0) : 0) {
+                // the skip of level 0 is never consumed (5 up-samplers for 6 skips, temporalunet.py:31-32,66-67): not even written
+                TH sk{-1, dm[i + 1], x.L};
+                TH xo = emit_level(LV_DOWN, lvv, x, nullptr, inv.down_w[i], inv.down_b[i], i > 0, &sk);
+                pool.put(x.buf);
+                skips.push_back(sk);
+                x = xo;
+                tapr.push_back({i, x.buf, x.C, x.L});
+                pool.pin(x.buf);
                 continue;
             }
+            TH a = emit_rcb(x, nullptr);
+            pool.put(x.buf);  // the block input is dead once both consumers (conv1, residual) are emitted
+            TH b = emit_rcb(a, nullptr);
+            pool.put(a.buf);
+            skips.push_back(b);
+            if (i != nd - 1) {
+                int Lout = (b.L - 1) / 2 + 1;
+                if (sw.fused && wrs_supported(dm[i + 1], b.C, b.L, false)) {
+                    size_t w = pk.resample_frag(params + inv.down_w[i].off, dm[i + 1], dm[i + 1], 3, false);
+                    size_t bb = pk.vec(params + inv.down_b[i].off, dm[i + 1]);
+                    x = emit_wrs(b, w, bb, dm[i + 1], WK_DOWN, 3, Lout);
+                } else {
+                    size_t w = pk.conv(params + inv.down_w[i].off, dm[i + 1], dm[i + 1], 3, dm[i + 1]);
+                    size_t bb = pk.vec(params + inv.down_b[i].off, dm[i + 1]);
+                    x = emit_conv(b, nullptr, dm[i + 1], w, bb, dm[i + 1], 3, 2, 1, false, Lout);
+                }
+            } else {
+                x = b;
+            }
+            tapr.push_back({i, x.buf, x.C, x.L});
+            pool.pin(x.buf);
         }
-        TH a = emit_rcb(x, &sk);
-        pool.put(x.buf);
-        pool.put(sk.buf);
-        TH b = emit_rcb(a, nullptr);
-        pool.put(a.buf);
-        int Lout = 2 * b.L;
-        if (Lout == 8 || Lout == 14 || Lout == 26) Lout -= 1;  // crop rule, temporalunet.py:70-71
-        if (use_fused && wrs_supported(dm[i - 1], b.C, b.L, true)) {
-            size_t w = pk.resample_frag(params + inv.up_w[j].off, dm[i - 1], dm[i - 1], 4, true);
-            size_t bb = pk.vec(params + inv.up_b[j].off, dm[i - 1]);
-            x = emit_wrs(b, w, bb, dm[i - 1], WK_UP, 4, Lout);
-        } else {
-            size_t w = pk.convT(params + inv.up_w[j].off, dm[i - 1], dm[i - 1], 4);
-            size_t bb = pk.vec(params + inv.up_b[j].off, dm[i - 1]);
-            x = emit_conv(b, nullptr, dm[i - 1], w, bb, dm[i - 1], 4, 2, 1, true, Lout);
+        {
+            // middle: input is skips.back() (same buffer, must stay alive for the up path)
+            TH a = emit_rcb(x, nullptr);
+            TH b = emit_rcb(a, nullptr);
+            pool.put(a.buf);
+            x = b;
+            tapr.push_back({100, x.buf, x.C, x.L});
+            pool.pin(x.buf);
         }
-        pool.put(b.buf);
-        tapr.push_back({200 + j, x.buf, x.C, x.L});
-        pool.pin(x.buf);
-    }
-    EDMP_REQUIRE(x.L == N, "decoder output length %d != horizon %d", x.L, N);
-    // final Conv1dBlock + 1x1 head
-    if (!final_fused) {
-        size_t w = pk.conv(params + inv.final_cb.w.off, dm[1], dm[1], 5, dm[1]);
-        size_t b = pk.vec(params + inv.final_cb.b.off, dm[1]);
-        size_t g = pk.vec(params + inv.final_cb.gw.off, dm[1]), be = pk.vec(params + inv.final_cb.gb.off, dm[1]);
-        TH y = emit_conv(x, nullptr, dm[1], w, b, dm[1], 5, 1, 2, false, N);
-        emit_gn(y, g, be, -1, -1);
-        pool.put(x.buf);
-        x = y;
-    }
-    size_t hw = pk.vec(params + inv.final_w.off, desc->input_dim * dm[1]);
-    size_t hb = pk.vec(params + inv.final_b.off, desc->input_dim);
-    const double head_flops = 2.0 * N * desc->input_dim * dm[1];
+        for (int j = 0, i = nd; i > 1; --i, ++j) {
+            TH sk = skips.back();
+            skips.pop_back();
+            EDMP_REQUIRE(sk.L == x.L && sk.C == x.C, "skip/upsample shape mismatch at up level %d (L %d vs %d)", j, sk.L, x.L);
+            EDMP_REQUIRE(sk.buf >= 0, "up level %d consumes a skip tensor that the fused down level did not write", j);
+            {
+                const bool last = (i == 2);
+                const int mode = (last && dm[1] == dm[i - 1] && 2 * x.L == N) ? LV_UP_FINAL : LV_UP;
+                if (const int lvv = sw.level ? level_variant(mode, dm[i - 1], x.L, x.C, sk.C) : 0) {
+                    TH xo = emit_level(mode, lvv, x, &sk, inv.up_w[j], inv.up_b[j], false, nullptr);
+                    pool.put(x.buf);
+                    pool.put(sk.buf);
+                    x = xo;
+                    if (mode == LV_UP_FINAL) {
+                        final_fused = true;  // the level kernel already applied final_conv.0
+                    } else {
+                        tapr.push_back({200 + j, x.buf, x.C, x.L});
+                        pool.pin(x.buf);
+                    }
+                    continue;
+                }
+            }
+            TH a = emit_rcb(x, &sk);
+            pool.put(x.buf);
+            pool.put(sk.buf);
+            TH b = emit_rcb(a, nullptr);
+            pool.put(a.buf);
+            int Lout = 2 * b.L;
+            if (Lout == 8 || Lout == 14 || Lout == 26) Lout -= 1;  // crop rule, temporalunet.py:70-71
+            if (sw.fused && wrs_supported(dm[i - 1], b.C, b.L, true)) {
+                size_t w = pk.resample_frag(params + inv.up_w[j].off, dm[i - 1], dm[i - 1], 4, true);
+                size_t bb = pk.vec(params + inv.up_b[j].off, dm[i - 1]);
+                x = emit_wrs(b, w, bb, dm[i - 1], WK_UP, 4, Lout);
+            } else {
+                size_t w = pk.convT(params + inv.up_w[j].off, dm[i - 1], dm[i - 1], 4);
+                size_t bb = pk.vec(params + inv.up_b[j].off, dm[i - 1]);
+                x = emit_conv(b, nullptr, dm[i - 1], w, bb, dm[i - 1], 4, 2, 1, true, Lout);
+            }
+            pool.put(b.buf);
+            tapr.push_back({200 + j, x.buf, x.C, x.L});
+            pool.pin(x.buf);
+        }
+        EDMP_REQUIRE(x.L == N, "decoder output length %d != horizon %d", x.L, N);
+        // final Conv1dBlock + 1x1 head
+        if (!final_fused) {
+            size_t w = pk.conv(params + inv.final_cb.w.off, dm[1], dm[1], 5, dm[1]);
+            size_t b = pk.vec(params + inv.final_cb.b.off, dm[1]);
+            size_t g = pk.vec(params + inv.final_cb.gw.off, dm[1]), be = pk.vec(params + inv.final_cb.gb.off, dm[1]);
+            TH y = emit_conv(x, nullptr, dm[1], w, b, dm[1], 5, 1, 2, false, N);
+            emit_gn(y, g, be, -1, -1);
+            pool.put(x.buf);
+            x = y;
+        }
+        hw = pk.vec(params + inv.final_w.off, desc->input_dim * dm[1]);
+        hb = pk.vec(params + inv.final_b.off, desc->input_dim);
+        head_flops = 2.0 * N * desc->input_dim * dm[1];
 
-    // raw time-embedding weights for the table kernel
-    size_t o_t1w = pk.vec(params + inv.t1w.off, 4 * td * td), o_t1b = pk.vec(params + inv.t1b.off, 4 * td);
-    size_t o_t3w = pk.vec(params + inv.t3w.off, 4 * td * td), o_t3b = pk.vec(params + inv.t3b.off, td);
-    size_t o_tw = pk.vec(tw_all.data(), (int)tw_all.size()), o_tb = pk.vec(tb_all.data(), (int)tb_all.size());
-    u->tb_stride = tb_cursor;
+        // raw time-embedding weights for the table kernel
+        o_t1w = pk.vec(params + inv.t1w.off, 4 * td * td), o_t1b = pk.vec(params + inv.t1b.off, 4 * td);
+        o_t3w = pk.vec(params + inv.t3w.off, 4 * td * td), o_t3b = pk.vec(params + inv.t3b.off, td);
+        o_tw = pk.vec(tw_all.data(), (int)tw_all.size()), o_tb = pk.vec(tb_all.data(), (int)tb_all.size());
+        head_buf = x.buf;
+        for (auto& o : pops) EDMP_REQUIRE(!((o.kind == OP_GN || o.kind == OP_RCB) && o.res == -2), "identity residual over a channel concat is not supported");
+        return EDMP_OK;
+    }
+};
 
-    for (auto& o : pops) EDMP_REQUIRE(!((o.kind == OP_GN || o.kind == OP_RCB) && o.res == -2), "identity residual over a channel concat is not supported");
-    // allocate
-    size_t max_lc = (size_t)N * CP0;
-    for (auto& o : pops)
-        if (o.kind == OP_CONV || o.kind == OP_RCB || o.kind == OP_WRS || o.kind == OP_LVL) max_lc = std::max(max_lc, (size_t)std::max(o.Lout, o.Lin) * o.Cout);
-    u->buf_cap = max_lc * (size_t)max_batch;
-    u->layout = pk.layout_id(kPackVersion);
-    if (packed && packed_layout != u->layout) {
-        set_error("packed weight image has layout id %d, this library with the current builder switches packs %d: re-pack from the state dict", packed_layout, u->layout);
-        return EDMP_ERR_LAYOUT;
-    }
-    if (packed && (int64_t)pk.total != n_packed) {
-        set_error("packed weight image has %lld floats, this architecture / library layout needs %zu", (long long)n_packed, pk.total);
-        return EDMP_ERR_LAYOUT;
-    }
-    if (hipMalloc((void**)&u->wpack, pk.total * sizeof(float)) != hipSuccess) {
-        set_error("hipMalloc of %zu weight bytes failed", pk.total * sizeof(float));
-        return EDMP_ERR_HIP;
-    }
-    u->wpack_floats = pk.total;
-    EDMP_HIP_CHECK(hipMemcpy(u->wpack, packed ? packed : pk.host.data(), pk.total * sizeof(float), hipMemcpyHostToDevice));
-    for (int i = 0; i < pool.n; ++i) {
-        float* p = nullptr;
-        if (hipMalloc((void**)&p, u->buf_cap * sizeof(float)) != hipSuccess) {
-            set_error("hipMalloc of activation buffer %d (%zu bytes) failed", i, u->buf_cap * sizeof(float));
-            return EDMP_ERR_HIP;
-        }
-        u->bufs.push_back(p);
-    }
-    EDMP_HIP_CHECK(hipMalloc((void**)&u->tbias, (size_t)desc->T * u->tb_stride * sizeof(float)));
-    {
-        size_t sm = (size_t)(6 * td) * sizeof(float);
-        hipLaunchKernelGGL(time_table_kernel, dim3(desc->T), dim3(256), sm, ctx->stream, u->wpack + o_t1w, u->wpack + o_t1b,
-                           u->wpack + o_t3w, u->wpack + o_t3b, u->wpack + o_tw, u->wpack + o_tb, u->tbias, td, u->tb_stride);
-        EDMP_HIP_CHECK(hipGetLastError());
-        EDMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    }
-    // resolve program
+// ---- step 3: buffer ids / image offsets of the plan -> device pointers of the loaded model (the layer program unet_run_program walks)
+static void resolve_program(UNet* u, const LayerPlan& pl) {
+    const std::vector<POp>& pops = pl.pops;
     for (auto& o : pops) {
         Op op{};
         op.kind = o.kind;
@@ -1415,15 +1385,86 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
         op_kernel_name(op, op.name);
         u->prog.push_back(op);
     }
-    u->flops_nominal += head_flops;
-    u->flops_exec += head_flops;
-    u->flops_direct += head_flops;
-    u->x_in = u->bufs[x_in_buf];
-    u->h_last = u->bufs[x.buf];
-    u->head_w = u->wpack + hw;
-    u->head_b = u->wpack + hb;
-    u->head_cin = dm[1];
-    for (auto& t : tapr) u->taps.push_back({t.which, u->bufs[t.buf], t.C, t.L});
+}
+
+// builds the layer program + device weight image.  packed == nullptr: repack `params` (state-dict order) on the host;
+// otherwise `packed` IS the device image (edmp_unet_read_packed of the same architecture): only the layout is computed
+static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* params, int64_t n_params, int max_batch, const float* packed,
+                      int64_t n_packed, int packed_layout) {
+    ctx->epoch++;
+    EDMP_REQUIRE(desc->n_levels >= 2 && desc->n_levels <= EDMP_MAX_LEVELS, "n_levels out of range");
+    EDMP_REQUIRE(desc->input_dim >= 1 && desc->input_dim <= 8, "input_dim must be in 1..8");
+    EDMP_REQUIRE(desc->time_dim >= 4 && desc->time_dim % 2 == 0, "time_dim must be even");
+    EDMP_REQUIRE(max_batch >= 1, "max_batch must be positive");
+    for (int i = 0; i < desc->n_levels; ++i) EDMP_REQUIRE(desc->dims[i] % 8 == 0 && desc->dims[i] >= 8, "dims must be multiples of 8");
+    RawNet inv = inventory(*desc);
+    static const float no_params = 0.0f;
+    if (packed) {  // layout-only pass: the builder computes offsets from `params` but never reads through it (Packer::dry)
+        params = &no_params;
+        n_params = inv.total;
+    }
+    EDMP_REQUIRE(inv.total == n_params, "parameter blob has %lld floats, architecture needs %lld", (long long)n_params, (long long)inv.total);
+    EDMP_HIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->unet) {
+        unet_destroy(ctx->unet);
+        ctx->unet = nullptr;
+    }
+    // owned here until the build has succeeded: every early return below (argument checks, failed allocations / copies /
+    // launches) releases the weight image and the activation buffers
+    std::unique_ptr<UNet, void (*)(UNet*)> guard(new UNet(), unet_destroy);
+    UNet* u = guard.get();
+    u->desc = *desc;
+    u->max_batch = max_batch;
+    u->fuse_tail = fuse_tail();
+    LayerPlan pl(desc, params, packed != nullptr);
+    if (int rc = pl.plan()) return rc;
+    u->tb_stride = pl.tb_cursor;
+    // ---- step 2: device image, activation buffers, time-bias table
+    size_t max_lc = (size_t)pl.N * pl.CP0;
+    for (auto& o : pl.pops)
+        if (o.kind == OP_CONV || o.kind == OP_RCB || o.kind == OP_WRS || o.kind == OP_LVL) max_lc = std::max(max_lc, (size_t)std::max(o.Lout, o.Lin) * o.Cout);
+    u->buf_cap = max_lc * (size_t)max_batch;
+    u->layout = pl.pk.layout_id(kPackVersion);
+    if (packed && packed_layout != u->layout) {
+        set_error("packed weight image has layout id %d, this library with the current builder switches packs %d: re-pack from the state dict", packed_layout, u->layout);
+        return EDMP_ERR_LAYOUT;
+    }
+    if (packed && (int64_t)pl.pk.total != n_packed) {
+        set_error("packed weight image has %lld floats, this architecture / library layout needs %zu", (long long)n_packed, pl.pk.total);
+        return EDMP_ERR_LAYOUT;
+    }
+    if (hipMalloc((void**)&u->wpack, pl.pk.total * sizeof(float)) != hipSuccess) {
+        set_error("hipMalloc of %zu weight bytes failed", pl.pk.total * sizeof(float));
+        return EDMP_ERR_HIP;
+    }
+    u->wpack_floats = pl.pk.total;
+    EDMP_HIP_CHECK(hipMemcpy(u->wpack, packed ? packed : pl.pk.host.data(), pl.pk.total * sizeof(float), hipMemcpyHostToDevice));
+    for (int i = 0; i < pl.pool.n; ++i) {
+        float* p = nullptr;
+        if (hipMalloc((void**)&p, u->buf_cap * sizeof(float)) != hipSuccess) {
+            set_error("hipMalloc of activation buffer %d (%zu bytes) failed", i, u->buf_cap * sizeof(float));
+            return EDMP_ERR_HIP;
+        }
+        u->bufs.push_back(p);
+    }
+    EDMP_HIP_CHECK(hipMalloc((void**)&u->tbias, (size_t)desc->T * u->tb_stride * sizeof(float)));
+    {
+        size_t sm = (size_t)(6 * pl.td) * sizeof(float);
+        hipLaunchKernelGGL(time_table_kernel, dim3(desc->T), dim3(256), sm, ctx->stream, u->wpack + pl.o_t1w, u->wpack + pl.o_t1b,
+                           u->wpack + pl.o_t3w, u->wpack + pl.o_t3b, u->wpack + pl.o_tw, u->wpack + pl.o_tb, u->tbias, pl.td, u->tb_stride);
+        EDMP_HIP_CHECK(hipGetLastError());
+        EDMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    resolve_program(u, pl);
+    u->flops_nominal += pl.head_flops;
+    u->flops_exec += pl.head_flops;
+    u->flops_direct += pl.head_flops;
+    u->x_in = u->bufs[pl.x_in_buf];
+    u->h_last = u->bufs[pl.head_buf];
+    u->head_w = u->wpack + pl.hw;
+    u->head_b = u->wpack + pl.hb;
+    u->head_cin = pl.dm[1];
+    for (auto& t : pl.tapr) u->taps.push_back({t.which, u->bufs[t.buf], t.C, t.L});
     ctx->unet = guard.release();
     return EDMP_OK;
 }
