@@ -471,6 +471,7 @@ extern "C" void edmp_ctx_destroy(edmp_ctx* ctx) {
         (void)hipStreamSynchronize(ctx->side_stream);
         (void)hipStreamDestroy(ctx->side_stream);
     }
+    if (ctx->chain_abort) (void)hipHostFree(ctx->chain_abort);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

@@ -173,15 +173,17 @@ struct WideAcc<16> {
     using type = __attribute__((ext_vector_type(4))) float;
 };
 
-// weight-fragment stream of one conv in HBM: [Cout/SW][Cin/KG][NSLAB][64 lanes][4] floats (pack_fragments)
-// The parameters every workgroup needs before it can request its first bytes are leading scalar kernel arguments: with
-// -mllvm -amdgpu-kernarg-preload-count=12 the command processor delivers them in SGPRs at wave launch, no scalar-memory round
-// trip in front of the first loads (the struct `pr` carries the rest; its copies of these fields are ignored)
-template <int KIND, int MS, int CG, int GS, int LIN, bool RES>
-__global__ __launch_bounds__(256) void wide_conv_kernel(const float* a_src1, const float* a_src2, const float* a_W, int a_C1, int a_C2, int a_Cout, int a_B,
-                                                        int a_gx_shift, int a_ng_shift, RcbP pr) {
-    RcbP p = pr;
-    p.src1 = a_src1, p.src2 = a_src2, p.W = a_W, p.C1 = a_C1, p.C2 = a_C2, p.Cout = a_Cout, p.B = a_B, p.gx_shift = a_gx_shift, p.ng_shift = a_ng_shift;
+// No gate: the stand-alone kernel.  A gate (chain.hip: the cluster barrier of a persistent layer chain) is called once in the
+// prologue, after everything that does not depend on other workgroups has been requested (weight fragments of chunk 0, epilogue
+// operands) and before the first activation load.
+struct WideNoGate {
+    static constexpr bool kGated = false;
+    __device__ __forceinline__ void operator()() const {}
+};
+
+// The work of one workgroup: tile (channel group `grp`, sample tile `tile`) of the conv `p`; `lds` = the workgroup's dynamic LDS.
+template <int KIND, int MS, int CG, int GS, int LIN, bool RES, class Gate>
+__device__ __forceinline__ void wide_conv_body(const RcbP& p, const int grp, const int tile, float* lds, Gate gate) {
     using Cf = WideCfg<KIND, MS, CG, GS, LIN, RES>;
     using acc_t = typename WideAcc<MS>::type;
     constexpr int L = Cf::L, LLOAD = Cf::LLOAD, LOUT = Cf::LOUT, LACC = Cf::LACC, SW = Cf::SW, KG = Cf::KG, AR = Cf::AR;
@@ -190,30 +192,12 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(const float* a_src1, con
     constexpr int S = Cf::S, KC = Cf::KC, QW = Cf::QW, LDK = Cf::LDK, NTAP = Cf::NTAP, NSLAB = Cf::NSLAB;
     constexpr int A_FL = Cf::A_FL, NTH = Cf::NTH, A_F4 = Cf::A_F4, NA = Cf::NA, YS = Cf::YS, NP = Cf::NP;
     constexpr int NBLK = Cf::NBLK, NSIDE = Cf::NSIDE, NBL = Cf::NBL;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
 
     EDMP_STAMP(0, 0)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s = wave % S, ks = wave / S;
-    // workgroup -> (channel group, sample tile).  Consecutive workgroup ids go round-robin over the 8 XCDs (each with its own
-    // L2): gx = 2^gx_shift of the XCDs split the channel groups, 8 / gx split the sample tiles, so a weight stream is fetched from HBM by
-    // 8 / gx L2s and an activation tile by gx of them - the host picks the split with the least traffic (unet.hip: xcd_split)
-    int grp, tile;
-    {
-        // (shifts, not divisions: a runtime integer division is ~40 instructions in front of the first load)
-        const int lin = blockIdx.x;
-        if (p.gx_shift >= 0) {  // ng and gx are powers of two
-            const int xcd = lin & 7, j = lin >> 3, ngp_shift = p.ng_shift - p.gx_shift;
-            grp = ((j & ((1 << ngp_shift) - 1)) << p.gx_shift) + (xcd & ((1 << p.gx_shift) - 1));
-            tile = ((j >> ngp_shift) << (3 - p.gx_shift)) + (xcd >> p.gx_shift);
-        } else {
-            const int ng = p.Cout / CG;
-            grp = lin % ng;
-            tile = lin / ng;
-        }
-    }
     const int co0 = grp * CG;
     const int b0 = tile * MS;
     const int ch1 = p.C1 / KC, ch2 = p.C2 / KC;
@@ -320,13 +304,19 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(const float* a_src1, con
     // ---- prologue: weights of chunk 0 in flight, activation chunk 0 staged; chunks 1 and 2 are fetched and committed by the
     //      first K step, next to the fetch of chunk 3 (waiting for them here cost 1-2.5 us of every launch at L >= 4)
     f32x4 r1[NA];  // activation chunk 1 (the first step's extra staging set)
-    load_a(0, raB);  // first: its data is on the way to the first MFMA twice (commit, barrier, fragment read) ...
+    if constexpr (!Gate::kGated) load_a(0, raB);  // first: its data is on the way to the first MFMA twice (commit, barrier, fragment read) ...
     load_b(0, bA);   // ... the weights only once, and memory returns in request order
     // epilogue operands requested now (they land long before they are used; their pointers are not among the preloaded
     // kernel arguments, so anything earlier would put a scalar-memory wait in front of the loads above)
     const float bias_v = (ks == 0) ? p.bias[co0 + s * SW + (lane & (SW - 1))] : 0.0f;
     float rbias_v = 0.0f;
     if constexpr (RES) rbias_v = (ks == 0) ? p.res_bias[co0 + s * SW + (lane & (SW - 1))] : 0.0f;
+    if constexpr (Gate::kGated) {
+        // layer chain: weights and epilogue operands are in flight; now wait until the other workgroups of this sample tile's
+        // cluster have finished the previous layer, then fetch the activations they wrote
+        gate();
+        load_a(0, raB);
+    }
     commit_a(lds, raB);
     __syncthreads();
     EDMP_STAMP(0, 1)
@@ -690,6 +680,36 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(const float* a_src1, con
         }
     }
     EDMP_STAMP(0, 4)
+}
+
+// weight-fragment stream of one conv in HBM: [Cout/SW][Cin/KG][NSLAB][64 lanes][4] floats (pack_fragments)
+// The parameters every workgroup needs before it can request its first bytes are leading scalar kernel arguments: with
+// -mllvm -amdgpu-kernarg-preload-count=12 the command processor delivers them in SGPRs at wave launch, no scalar-memory round
+// trip in front of the first loads (the struct `pr` carries the rest; its copies of these fields are ignored)
+template <int KIND, int MS, int CG, int GS, int LIN, bool RES>
+__global__ __launch_bounds__(256) void wide_conv_kernel(const float* a_src1, const float* a_src2, const float* a_W, int a_C1, int a_C2, int a_Cout, int a_B,
+                                                        int a_gx_shift, int a_ng_shift, RcbP pr) {
+    RcbP p = pr;
+    p.src1 = a_src1, p.src2 = a_src2, p.W = a_W, p.C1 = a_C1, p.C2 = a_C2, p.Cout = a_Cout, p.B = a_B, p.gx_shift = a_gx_shift, p.ng_shift = a_ng_shift;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // workgroup -> (channel group, sample tile).  Consecutive workgroup ids go round-robin over the 8 XCDs (each with its own
+    // L2): gx = 2^gx_shift of the XCDs split the channel groups, 8 / gx split the sample tiles, so a weight stream is fetched from HBM by
+    // 8 / gx L2s and an activation tile by gx of them - the host picks the split with the least traffic (unet.hip: xcd_split)
+    int grp, tile;
+    {
+        // (shifts, not divisions: a runtime integer division is ~40 instructions in front of the first load)
+        const int lin = blockIdx.x;
+        if (p.gx_shift >= 0) {  // ng and gx are powers of two
+            const int xcd = lin & 7, j = lin >> 3, ngp_shift = p.ng_shift - p.gx_shift;
+            grp = ((j & ((1 << ngp_shift) - 1)) << p.gx_shift) + (xcd & ((1 << p.gx_shift) - 1));
+            tile = ((j >> ngp_shift) << (3 - p.gx_shift)) + (xcd >> p.gx_shift);
+        } else {
+            const int ng = p.Cout / CG;
+            grp = lin % ng;
+            tile = lin / ng;
+        }
+    }
+    wide_conv_body<KIND, MS, CG, GS, LIN, RES>(p, grp, tile, lds, WideNoGate{});
 }
 
 // host: [tap][Cout][Cin] (taps 0..4; tap index 5 = the folded residual 1x1 conv) -> fragment stream
