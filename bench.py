@@ -41,9 +41,9 @@ def effective_cores() -> int:
 
 
 def pmc_traffic():
-    """HBM MB per conv-family launch from the committed rocprofv3 PMC passes (profiles/r03_pmc_hbm_traffic.json, else
+    """HBM MB per conv-family launch from the committed rocprofv3 PMC passes (profiles/r04_pmc_hbm_traffic.json, else
     an earlier round's; produced by scripts/pmc_unet_forward.py + scripts/summarize_pmc.py).  Counters cannot be read live."""
-    for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+    for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)["conv_family"]

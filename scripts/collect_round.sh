@@ -1,0 +1,13 @@
+#!/bin/bash
+# After `ROUND=rNN scripts/gpu_round.sh` ran on a GPU box (gpurun merges gpurun_out/rNN/ back): copy that run's summaries into profiles/
+# (tracked) WITHOUT touching the raw output, and derive the numbers profiles/README.md quotes from the committed files.
+R=${1:-r04}
+O=gpurun_out/$R
+set -e
+cp $O/bench.json profiles/${R}_bench.json
+cp $O/kernel_stats.csv profiles/${R}_kernel_stats.csv
+cp $O/profile_summary.json profiles/${R}_profile_summary.json
+cp $O/pmc_hbm_traffic.json profiles/${R}_pmc_hbm_traffic.json
+cp $O/pmc_mfma_util.md profiles/${R}_pmc_mfma_util.md
+python scripts/round_numbers.py $R > profiles/${R}_numbers.md
+cat profiles/${R}_numbers.md

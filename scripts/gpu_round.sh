@@ -1,7 +1,8 @@
 #!/bin/bash
 # Run on the GPU box by gpurun: bench.py, the rocprofv3 kernel trace of the same command, and the PMC passes
-# (FETCH_SIZE / WRITE_SIZE / MFMA busy, each its own run, --kernel-trace only).  Outputs -> gpurun_out/\$ROUND/ (default r03).
-O=gpurun_out/${ROUND:-r03}
+# (FETCH_SIZE / WRITE_SIZE / MFMA busy, each its own run, --kernel-trace only).  Outputs -> gpurun_out/\$ROUND/ (default r04); raw
+# output stays there untouched, scripts/collect_round.sh copies the summaries into profiles/ and derives profiles/<round>_numbers.md.
+O=gpurun_out/${ROUND:-r04}
 mkdir -p $O
 python bench.py --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err
 python scripts/show_bench.py $O/bench.json | cut -c1-220 | head -4
