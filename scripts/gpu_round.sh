@@ -8,7 +8,7 @@ python bench.py --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err
 python scripts/show_bench.py $O/bench.json | cut -c1-220 | head -4
 export TMPDIR=/tmp
 REPO=$PWD
-CMD="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline"
+CMD="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-two-scenes"  # (two scenes in flight would overlap kernels of two contexts: durations in the trace would no longer be one chain's)
 cd /tmp
 rm -rf $REPO/$O/prof $REPO/$O/pmc_*
 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$O/prof -o trace -- $CMD > $REPO/$O/prof_bench.json 2> $REPO/$O/prof.err

@@ -51,7 +51,7 @@ print(f"* conv family: {tot_ns / 1e6:.2f} ms in {calls} launches = {ncalls:.2f} 
       f"(bench live brackets: {rf['conv_ms_per_call']:.2f} ms, {rf['avg_launch_us']:.2f} us)")
 for r in sorted(rows, key=lambda r: -int(r["TotalDurationNs"]))[:6]:
     nm = re.sub(r"\(edmp::WideKind\)|\(edmp::LevelMode\)|void |edmp::", "", r["Name"].split("(")[0] if "<" not in r["Name"] else r["Name"])
-    print(f"* `{nm[:70]}`: {r['Calls']} calls, avg {int(r['AverageNs']) / 1e3:.2f} us, {float(r['Percentage']):.1f} %")
+    print(f"* `{nm[:70]}`: {r['Calls']} calls, avg {float(r['AverageNs']) / 1e3:.2f} us, {float(r['Percentage']):.1f} %")
 
 print(f"\n## PMC passes (`{R}_pmc_hbm_traffic.json`, `{R}_pmc_mfma_util.md`)\n")
 h = json.load(open(os.path.join(P, f"{R}_pmc_hbm_traffic.json")))["conv_family"]
