@@ -705,6 +705,22 @@ static int enqueue_chains(edmp_ctx* ctx, int K, const double* noise_dev, bool us
     }
     EDMP_HIP_CHECK(hipEventRecord(s->ev_fork, ctx->stream));
     for (int c = 1; c < K; ++c) EDMP_HIP_CHECK(hipStreamWaitEvent(sp[c].st, s->ev_fork, 0));
+    // an error in the middle leaves work of the other chains enqueued on their streams: drain them before the error travels up, so
+    // that nothing still runs on buffers the caller may release (the message of the first error is kept)
+    auto fail = [&](int code) {
+        const std::string msg = g_err;
+        for (int c = 1; c < K; ++c) (void)hipStreamSynchronize(sp[c].st);
+        g_err = msg;
+        return code;
+    };
+#define EDMP_CHAIN_HIP(expr)                                                                           \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_));            \
+            return fail(EDMP_ERR_HIP);                                                                 \
+        }                                                                                              \
+    } while (0)
     int gstep = 0;  // guided steps so far: selects the partial-sum buffer
     for (int t = t_hi; t > t_lo; --t) {
         const double* z = use_rng ? nullptr : noise_dev + (size_t)(t_hi - t) * n;
@@ -712,22 +728,23 @@ static int enqueue_chains(edmp_ctx* ctx, int K, const double* noise_dev, bool us
         const int buf = gstep & 1;
         for (int c = 0; c < K; ++c) {
             rc = step_a(ctx, s->X, z, B, t, zero_row0, guided, nullptr, nullptr, true, use_rng, seed, &sp[c], buf);
-            if (rc) return rc;
-            if (g) EDMP_HIP_CHECK(hipEventRecord(s->ev_grad[buf][c], sp[c].st));
+            if (rc) return fail(rc);
+            if (g) EDMP_CHAIN_HIP(hipEventRecord(s->ev_grad[buf][c], sp[c].st));
         }
         for (int c = 0; c < K; ++c) {
             if (g)  // the whole batch's partial sums are in place before any chain normalises by their total
                 for (int o = 0; o < K; ++o)
-                    if (o != c) EDMP_HIP_CHECK(hipStreamWaitEvent(sp[c].st, s->ev_grad[buf][o], 0));
+                    if (o != c) EDMP_CHAIN_HIP(hipStreamWaitEvent(sp[c].st, s->ev_grad[buf][o], 0));
             rc = step_b(ctx, s->X, B, t, guided, nullptr, true, &sp[c], buf);
-            if (rc) return rc;
+            if (rc) return fail(rc);
         }
         if (g) ++gstep;
     }
     for (int c = 1; c < K; ++c) {
-        EDMP_HIP_CHECK(hipEventRecord(s->ev_done[c], sp[c].st));
-        EDMP_HIP_CHECK(hipStreamWaitEvent(ctx->stream, s->ev_done[c], 0));
+        EDMP_CHAIN_HIP(hipEventRecord(s->ev_done[c], sp[c].st));
+        EDMP_CHAIN_HIP(hipStreamWaitEvent(ctx->stream, s->ev_done[c], 0));
     }
+#undef EDMP_CHAIN_HIP
     return EDMP_OK;
 }
 
