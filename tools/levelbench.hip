@@ -68,6 +68,27 @@ int main() {
             const unsigned cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 0x7;
             percu[xcc * 64 + se * 16 + sh * 8 + (cu & 7)]++;  // (layout of HW_ID is approximate: used only to count distinct slots)
         }
+        {   // per XCD: mean / max workgroup duration, and first vs second workgroup of a (xcc, hw id) slot
+            double sx[16] = {0}, mxx[16] = {0};
+            int nx[16] = {0};
+            for (int i = 0; i < nwg && i < 1024; ++i) {
+                const int x = (int)(wt[i][2] & 0xf);
+                const double d = (wt[i][1] - wt[i][0]) / 100.0;
+                sx[x] += d, nx[x]++, mxx[x] = d > mxx[x] ? d : mxx[x];
+            }
+            printf("  per XCD mean (max) workgroup duration, us:");
+            for (int x = 0; x < 16; ++x)
+                if (nx[x]) printf(" [%d] %.1f (%.1f)", x, sx[x] / nx[x], mxx[x]);
+            printf("\n");
+            double lo = 1e9, hi = 0;
+            int ilo = 0, ihi = 0;
+            for (int i = 0; i < nwg && i < 1024; ++i) {
+                const double d = (wt[i][1] - wt[i][0]) / 100.0;
+                if (d < lo) lo = d, ilo = i;
+                if (d > hi) hi = d, ihi = i;
+            }
+            printf("  fastest workgroup %d: %.1f us, slowest %d: %.1f us\n", ilo, lo, ihi, hi);
+        }
         int cus = 0, mx = 0;
         for (int v : percu) { cus += v > 0; mx = v > mx ? v : mx; }
         printf("  launch span %.2f us over %d workgroups | mean workgroup duration %.2f us | last start +%.2f us | distinct (xcc, hw id) slots %d, max workgroups on one %d | starts per us:", (t1 - t0) / 100.0, nwg, dur / nwg, late, cus, mx);
