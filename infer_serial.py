@@ -42,6 +42,18 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=
     T = benchmark_cfg["model"]["T"]
     num_channels = benchmark_cfg["model"]["num_channels"]
     if dataset is None:
+        # the reference's own dataset types (datasets/load_test_dataset.py:15-38: 'global' | 'hybrid' | 'both' -> <path>/<type>_solvable_problems.pkl):
+        # served from the JSON scripts/mpinets_pkl_to_json.py writes next to the pickle, when it is there
+        dtype, dpath = benchmark_cfg["dataset"]["dataset_type"], benchmark_cfg["dataset"]["path"]
+        converted = os.path.join(dpath, f"{dtype}_solvable_problems.json")
+        if dtype in ("global", "hybrid", "both"):
+            if not os.path.exists(converted):
+                raise FileNotFoundError(f"{converted} not found: convert {dtype}_solvable_problems.pkl with scripts/mpinets_pkl_to_json.py (IK goals via --ik-goals), "
+                                        "or use dataset_type: 'synthetic'")
+            from edmp_amd.scenes import ProblemSetDataset
+
+            dataset = ProblemSetDataset(converted)
+    if dataset is None:
         dataset = SyntheticDataset(benchmark_cfg["dataset"]["dataset_type"], d_path=benchmark_cfg["dataset"]["path"],
                                    scene_types=benchmark_cfg["dataset"]["scene_types"],
                                    num_scenes_per_type=benchmark_cfg["dataset"].get("num_scenes_per_type", 1))

@@ -651,6 +651,19 @@ def test_infer_serial_on_a_converted_problem_set(tmp_path):
     yaml.safe_dump(cfg, open(cj, "w"))
     ds = scenes.ProblemSetDataset(str(pj))
     res = infer_serial.run(str(cj), dataset=ds, verbose=False)
+    # ... and through the run config alone, the way the reference selects its dataset (dataset_type 'global' + path,
+    # datasets/load_test_dataset.py:15-38): <path>/global_solvable_problems.json is picked up
+    import shutil
+
+    shutil.copy(pj, tmp_path / "global_solvable_problems.json")
+    cfg["dataset"]["dataset_type"], cfg["dataset"]["path"] = "global", str(tmp_path)
+    cg = tmp_path / "cfgs" / "cfg_global.yaml"
+    yaml.safe_dump(cfg, open(cg, "w"))
+    np.random.seed(123)
+    res_a = infer_serial.run(str(cg), verbose=False)
+    np.random.seed(123)
+    res_b = infer_serial.run(str(cj), dataset=ds, verbose=False)
+    assert all(np.array_equal(a["trajectory"], b["trajectory"]) for a, b in zip(res_a, res_b))
     assert len(res) == 2 and all(r["scene_type"] == "tabletop" and np.isfinite(r["trajectory"]).all() for r in res)
     for k, r in enumerate(res):
         oc = ds.fetch_data(k, "tabletop")[0]

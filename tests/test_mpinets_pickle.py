@@ -200,3 +200,18 @@ def test_unpickler_refuses_foreign_code(tmp_path):
 
     with pytest.raises(pickle.UnpicklingError):
         conv.load_pickle(pickle.dumps({"tabletop": {"task_oriented": [Evil()]}}))
+
+
+def test_infer_serial_names_the_missing_converted_file(tmp_path):
+    """a run config with the reference's dataset types ('global' | 'hybrid' | 'both', datasets/load_test_dataset.py:15-38) looks for the
+    converted JSON next to where the pickle would be and says what to do when it is not there - before any GPU is touched"""
+    import yaml
+
+    import infer_serial
+
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "cfg_c1_plumbing.yaml")))
+    cfg["dataset"]["dataset_type"], cfg["dataset"]["path"] = "hybrid", str(tmp_path)
+    os.makedirs(tmp_path / "cfgs")
+    yaml.safe_dump(cfg, open(tmp_path / "cfgs" / "c.yaml", "w"))
+    with pytest.raises(FileNotFoundError, match="mpinets_pkl_to_json"):
+        infer_serial.run(str(tmp_path / "cfgs" / "c.yaml"), verbose=False)
