@@ -25,8 +25,50 @@ from edmp_amd.scenes import SyntheticDataset
 from edmp_amd.temporalunet import TemporalUNet
 
 
-def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=1):
-    """The reference's scene loop (infer_serial.py:95-170).  ``scenes_in_flight`` > 1 (an extension; the reference is serial) plans
+def _ranks(device):
+    """Launched under ``python -m torch.distributed.run --nproc-per-node N infer_serial.py ...`` (one process per GPU): join the
+    process group and return (rank, world, this rank's device).  Backend "nccl" (= RCCL) when every local rank has its own GPU,
+    EDMP_DIST_BACKEND=gloo lets the ranks share one (single-GPU test boxes), as in bench.py.  Outside a launcher: (0, 1, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1, device
+    import torch.distributed as dist
+
+    backend = os.environ.get("EDMP_DIST_BACKEND", "nccl")
+    local, ngpu = int(os.environ.get("LOCAL_RANK", "0")), torch.cuda.device_count()
+    if backend == "nccl" and ngpu < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+        raise SystemExit(f"[infer_serial] {world} ranks over RCCL need one GPU each, this node shows {ngpu}: launch fewer ranks (or EDMP_DIST_BACKEND=gloo to share)")
+    index = local if backend == "nccl" else local % max(ngpu, 1)
+    torch.cuda.set_device(index)
+    if not dist.is_initialized():
+        dist.init_process_group(backend, **({"device_id": torch.device("cuda", index)} if backend == "nccl" else {}))
+    return dist.get_rank(), dist.get_world_size(), f"cuda:{index}"
+
+
+def job_summary(results, world=1):
+    """This rank's tallies; under a launcher the sum over all ranks (all_gather_object of five small integers per rank - the
+    trajectories stay where they were planned).  Keys: scenes, success_proxy (the reference's tally), success_strict, rows_collision_free, rows."""
+    mine = dict(scenes=len(results), success_proxy=sum(r["success_proxy"] for r in results), success_strict=sum(r["success_strict"] for r in results),
+                rows_collision_free=sum(r["rows_collision_free"] for r in results), rows=sum(r["rows"] for r in results),
+                planning_time_s=float(sum(r["planning_time_s"] for r in results)))
+    if world <= 1:
+        return dict(mine, ranks=1)
+    import torch.distributed as dist
+
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    out = {k: sum(p[k] for p in parts) for k in mine}
+    out["ranks"] = world
+    out["scenes_per_rank"] = [p["scenes"] for p in parts]
+    return out
+
+
+def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=1, shard_scenes=True):
+    """The reference's scene loop (infer_serial.py:95-170).  Under ``torch.distributed.run`` (one process per GPU, extension: the
+    reference is one process) the scenes are dealt round-robin to the ranks - scene i of the cfg's order goes to rank i mod world -
+    and nothing is exchanged until `job_summary` adds the tallies up: scenes are independent problems, this is the problem set's natural
+    shard (SURVEY.md 8e "replicas + final gather").  Every rank draws from its OWN process-global NumPy RandomState, as N separate
+    runs of the reference would (the reference never seeds it, infer_serial.py has no np.random.seed).  ``scenes_in_flight`` > 1 (an extension; the reference is serial) plans
     that many scenes concurrently on one GPU, each on its own context / stream / host thread: every launch of the sampler is one
     wave of 256 workgroups, a second independent scene fills its dispatch gaps and kernel tails (+6.7 % throughput measured,
     bench.py: two_scenes_in_flight).  Per-scene results are identical to the serial loop's: scenes are prepared in order on the
@@ -37,7 +79,7 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=
     from edmp_amd.runtime import get_context, lane_context
 
     benchmark_cfg = GC.load_yaml(cfg_path)
-    device = benchmark_cfg["model"]["device"]
+    rank, world, device = _ranks(benchmark_cfg["model"]["device"]) if shard_scenes else (0, 1, benchmark_cfg["model"]["device"])
     traj_len = benchmark_cfg["model"]["traj_len"]
     T = benchmark_cfg["model"]["T"]
     num_channels = benchmark_cfg["model"]["num_channels"]
@@ -61,7 +103,7 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=
     total_batch_size = guide_cfgs["total_batch_size"]
     model_name = benchmark_cfg["model"]["model_dir"] + "TemporalUNetModel" + str(T) + "_N" + str(traj_len)
     if not os.path.exists(model_name):
-        if verbose:
+        if verbose and rank == 0:
             print(f"[infer_serial] {model_name} not found: using a seeded random-init denoiser (no trained weights offline)")
         model_name = None
     k = max(1, int(scenes_in_flight))
@@ -100,7 +142,7 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=
         t_success += r["success_proxy"]  # the reference's tally: collision-free (infer_serial.py:165-168 on lib/environment.py:672)
         t_strict += r["success_strict"]
         if verbose:
-            print(f"Scene {len(results)} ({r['scene_type']}/{r['scene_num']}): planning {r['planning_time_s']:.2f} s, best row {r['best_row']}, swept volume "
+            print(("" if world == 1 else f"[rank {rank}] ") + f"Scene {len(results)} ({r['scene_type']}/{r['scene_num']}): planning {r['planning_time_s']:.2f} s, best row {r['best_row']}, swept volume "
                   f"{r['swept_volume']:.4g}, geometric success (proxy, collision-free) {r['success_proxy']} ({r['rows_collision_free']}/{r['rows']} rows of the batch); "
                   f"also within the joint limits {r['success_strict']} ({r['rows_ok']}/{r['rows']})   running {t_success}/{len(results)} (strict {t_strict}/{len(results)})")
 
@@ -109,7 +151,10 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=
             for scene_num in range(dataset.data_nums[scene_type]):
                 if max_scenes is not None and i >= max_scenes:
                     break
-                lane = i % k
+                if i % world != rank:  # another rank's scene
+                    i += 1
+                    continue
+                lane = (i // world) % k
                 while len(pending) >= k:  # the lane's previous scene (and every earlier one) is done before its context is reused
                     collect(pending.pop(0))
                 obstacle_config, _, _, num_cuboids, num_cylinders, start_joints, all_ik_goals = dataset.fetch_data(scene_num=scene_num, scene_type=scene_type)
@@ -135,12 +180,36 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=
                 i += 1
         while pending:
             collect(pending.pop(0))
+    if world > 1 or verbose:
+        summary = job_summary(results, world)
+        if verbose and rank == 0:
+            print(f"[infer_serial] {summary['scenes']} scenes on {summary['ranks']} rank(s): success (proxy, collision-free) {summary['success_proxy']}/{summary['scenes']}, "
+                  f"strict {summary['success_strict']}/{summary['scenes']}, rows collision-free {summary['rows_collision_free']}/{summary['rows']}")
+        run.last_summary = summary
+    return results
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(prog="Benchmarking Diffusion", description="Benchmarking with IK on Test sets")
+    parser.add_argument("-c", "--cfg_path", type=str, default="./configs/cfg_c1_plumbing.yaml")
+    parser.add_argument("--scenes-in-flight", type=int, default=1, help="plan this many scenes concurrently on the GPU (extension; the reference is serial)")
+    parser.add_argument("--max-scenes", type=int, default=None, help="stop after this many scenes of the cfg's order (all ranks together)")
+    parser.add_argument("--seed", type=int, default=None, help="np.random.seed(seed + rank) before the loop (the reference never seeds; for repeatable runs)")
+    parser.add_argument("--results-json", type=str, default=None, help="write this rank's per-scene results (without the trajectories) and the job summary "
+                                                                       "to PATH (rank 0) / PATH.rank<r> (other ranks)")
+    args = parser.parse_args(argv)
+    rank = int(os.environ.get("RANK", "0"))
+    if args.seed is not None:
+        np.random.seed(args.seed + rank)
+    results = run(args.cfg_path, scenes_in_flight=args.scenes_in_flight, max_scenes=args.max_scenes)
+    if args.results_json:
+        import json
+
+        rows = [{k: v for k, v in r.items() if k != "trajectory"} for r in results]
+        with open(args.results_json + ("" if rank == 0 else f".rank{rank}"), "w") as f:
+            json.dump({"rank": rank, "summary": getattr(run, "last_summary", None), "scenes": rows}, f, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
     return results
 
 
 if __name__ == "__main__":
-    parser = argparse.ArgumentParser(prog="Benchmarking Diffusion", description="Benchmarking with IK on Test sets")
-    parser.add_argument("-c", "--cfg_path", type=str, default="./configs/cfg_c1_plumbing.yaml")
-    parser.add_argument("--scenes-in-flight", type=int, default=1, help="plan this many scenes concurrently on the GPU (extension; the reference is serial)")
-    args = parser.parse_args()
-    run(args.cfg_path, scenes_in_flight=args.scenes_in_flight)
+    main()

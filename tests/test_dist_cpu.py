@@ -88,3 +88,32 @@ def test_geometric_success_proxy():
     outside = inside.copy()
     outside[3, 10] = 0.5  # joint 4 upper limit is -4 deg
     assert not ED.geometric_success(0.0, outside)
+
+
+def _summary_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import infer_serial
+
+    # rank r planned the scenes i with i % world == r of a five-scene problem set (infer_serial.run's deal): 3 + 2
+    mine = [dict(success_proxy=int(i % 3 == 0), success_strict=0, rows_collision_free=i, rows=4, planning_time_s=0.25) for i in range(5) if i % world == rank]
+    q.put((rank, infer_serial.job_summary(mine, world)))
+    dist.destroy_process_group()
+
+
+def test_scene_sharded_driver_summary_world2():
+    """infer_serial under a launcher: scenes are dealt round-robin, only the tallies meet at the end (all_gather_object)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_summary_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = dict(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = dict(scenes=5, success_proxy=2, success_strict=0, rows_collision_free=10, rows=20, planning_time_s=1.25, ranks=2, scenes_per_rank=[3, 2])
+    assert out[0] == out[1] == want

@@ -694,6 +694,51 @@ def test_infer_serial_two_scenes_in_flight():
     assert not np.array_equal(out[0][0]["trajectory"], out[0][1]["trajectory"])  # different scenes, different noise
 
 
+def test_infer_serial_scene_sharded_over_two_ranks(tmp_path):
+    """the reference-shaped driver under `python -m torch.distributed.run --nproc-per-node 2` (one process per GPU; gloo over the
+    one GPU of a test box, RCCL with two): scene i goes to rank i mod 2, nothing is exchanged until the tallies are summed, and
+    rank 0's first scene is what a single-process run plans first under the same seed."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    import yaml
+
+    import infer_serial
+    from tests.conftest import ROOT
+
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "cfg_c1_plumbing.yaml")))
+    cfg["dataset"]["num_scenes_per_type"] = 3
+    os.makedirs(tmp_path / "cfgs")
+    cj = tmp_path / "cfgs" / "cfg_three_scenes.yaml"
+    yaml.safe_dump(cfg, open(cj, "w"))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.device_count() < 2:
+        env["EDMP_DIST_BACKEND"] = "gloo"
+    out = tmp_path / "res.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "infer_serial.py"), "-c", str(cj), "--seed", "5", "--results-json", str(out)]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    d0, d1 = json.load(open(out)), json.load(open(str(out) + ".rank1"))
+    assert [x["scene_num"] for x in d0["scenes"]] == [0, 2] and [x["scene_num"] for x in d1["scenes"]] == [1]
+    sm = d0["summary"]
+    assert sm == d1["summary"] and sm["ranks"] == 2 and sm["scenes"] == 3 and sm["scenes_per_rank"] == [2, 1] and sm["rows"] == 12
+    assert sm["success_proxy"] == sum(x["success_proxy"] for x in d0["scenes"] + d1["scenes"])
+    assert "3 scenes on 2 rank(s)" in r.stdout
+    np.random.seed(5)
+    one = infer_serial.run(str(cj), verbose=False, max_scenes=1)
+    a, b = one[0], d0["scenes"][0]
+    assert (a["best_row"], a["success_proxy"], a["rows_collision_free"]) == (b["best_row"], b["success_proxy"], b["rows_collision_free"]) and a["swept_volume"] == b["swept_volume"]
+
+
 def test_device_noise_mode(tiny_net):
     """noise="device" (Philox on the GPU, explicitly non-parity): statistics of the stream, determinism, seed / step
     independence, and the loop driven by it equals the loop driven by the materialised stream."""

@@ -267,3 +267,16 @@ def test_bench_refuses_a_multi_gpu_run_it_cannot_honour():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env={**env, "WORLD_SIZE": "4", "EDMP_DIST_BACKEND": "gloo"}, capture_output=True, text=True,
                        timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and "{" not in r.stdout
+
+
+def test_infer_serial_job_summary_and_rank_detection(monkeypatch):
+    """the scene-sharded driver's host logic: outside a launcher there is one rank on the cfg's device; the job summary adds the
+    per-scene tallies up (the collective half runs in tests/test_dist_cpu.py)."""
+    import infer_serial
+
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert infer_serial._ranks("cuda:0") == (0, 1, "cuda:0")
+    res = [dict(success_proxy=1, success_strict=0, rows_collision_free=3, rows=4, planning_time_s=0.5), dict(success_proxy=0, success_strict=0, rows_collision_free=0, rows=4, planning_time_s=0.25)]
+    s = infer_serial.job_summary(res)
+    assert s == dict(scenes=2, success_proxy=1, success_strict=0, rows_collision_free=3, rows=8, planning_time_s=0.75, ranks=1)
