@@ -70,7 +70,7 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=
     shard (SURVEY.md 8e "replicas + final gather").  Every rank draws from its OWN process-global NumPy RandomState, as N separate
     runs of the reference would (the reference never seeds it, infer_serial.py has no np.random.seed).  ``scenes_in_flight`` > 1 (an extension; the reference is serial) plans
     that many scenes concurrently on one GPU, each on its own context / stream / host thread: every launch of the sampler is one
-    wave of 256 workgroups, a second independent scene fills its dispatch gaps and kernel tails (+6.7 % throughput measured,
+    wave of 256 workgroups, a second independent scene fills its dispatch gaps and kernel tails (+7-9 % throughput measured,
     bench.py: two_scenes_in_flight).  Per-scene results are identical to the serial loop's: scenes are prepared in order on the
     calling thread and each scene's noise is drawn there from the global NumPy RandomState, in the order the serial loop draws it."""
     from concurrent.futures import ThreadPoolExecutor
