@@ -84,8 +84,6 @@ struct edmp_ctx {
     edmp::Sampler* sampler = nullptr;
     edmp::Prof prof;
     uint64_t epoch = 0;  // bumped whenever device pointers / tables a captured hipGraph baked in may have changed
-    int chain_ok = -1;         // persistent layer chains (chain.hip): -1 not probed yet | 0 this GPU's workgroup -> XCD mapping rules them out | 1 usable
-    int* chain_abort = nullptr;  // host-mapped flag a chain kernel raises when a bounded cluster wait expires
 };
 
 namespace edmp {

@@ -48,8 +48,6 @@ struct RcbP {
     int gx_shift = -1, ng_shift = -1;  // wide_conv_kernel: log2 of the XCDs across the channel groups (wide.hip: xcd_split) and of the group count, set by the launcher; -1 = plain mapping
 };
 
-constexpr int kChainMaxOps = 16;  // layers one persistent layer chain can hold (chain.hip)
-
 // whole-level kernel (level.hip)
 enum LevelMode { LV_DOWN = 0, LV_UP = 1, LV_UP_FINAL = 2 };
 

@@ -471,7 +471,6 @@ extern "C" void edmp_ctx_destroy(edmp_ctx* ctx) {
         (void)hipStreamSynchronize(ctx->side_stream);
         (void)hipStreamDestroy(ctx->side_stream);
     }
-    if (ctx->chain_abort) (void)hipHostFree(ctx->chain_abort);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -641,7 +640,8 @@ extern "C" double* edmp_sumsq_ptr_dev(edmp_ctx* ctx) { return ctx ? guide_sumsq(
 
 // ---- row chains of one batch ---------------------------------------------------------------------------------------------
 // how many chains this call runs as: the configured count, 1 for runs that cannot be split (a cross-rank hook between the two
-// halves of a guided step, per-launch profiling brackets, hipGraph capture) or are too small to split on whole sample tiles
+// halves of a guided step, per-launch profiling brackets) or are too small to split on whole sample tiles.  A count > 1 switches
+// hipGraph replay off for the call (denoise_loop: `graph = ... && loop_chains(...) == 1`)
 static int loop_chains(edmp_ctx* ctx, int B, int guided) {
     Sampler* s = ctx->sampler;
     (void)guided;

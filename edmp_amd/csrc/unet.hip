@@ -160,15 +160,6 @@ struct UNet {
     double flops_nominal = 0, flops_exec = 0, flops_direct = 0;
     int layout = 0;  // layout id of the packed weight image (Packer::layout_id)
     bool fuse_tail = true;  // EDMP_NO_FUSED_TAIL at build time
-    // persistent layer chains (chain.hip): runs of consecutive program ops that one launch executes, found at build time
-    struct ChainSeg {
-        int first, n;              // ops [first, first + n) of prog
-        int inst[kChainMaxOps];
-    };
-    std::vector<ChainSeg> chains;
-    unsigned* chain_ctr = nullptr;  // [chain_tiles][kChainCtrWords] cluster counters, one cache line per cluster (zero between launches)
-    int chain_tiles = 0;
-    double flops_chain = 0;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -392,7 +383,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
 }  // namespace edmp
 #include "wide.hip"
 #include "level.hip"
-#include "chain.hip"
 #ifdef EDMP_SHARDED  // the position-tile and whole-level kernels are compiled in parallel translation units (kernel_shard.hip)
 #include "kernel_instances.h"
 namespace edmp {
@@ -720,7 +710,6 @@ void unet_destroy(UNet* u) {
     if (u->wpack) (void)hipFree(u->wpack);
     if (u->tbias) (void)hipFree(u->tbias);
     for (float* b : u->bufs) (void)hipFree(b);
-    if (u->chain_ctr) (void)hipFree(u->chain_ctr);
     delete u;
 }
 
@@ -1398,55 +1387,6 @@ static void resolve_program(UNet* u, const LayerPlan& pl) {
     }
 }
 
-// ---- step 4: which runs of the program a persistent layer chain (chain.hip) can execute: consecutive position-tile ops of the
-// 512-channel L = 2 block (Conv1dBlocks and the ConvTranspose behind them), at least two, on the main stream.  OPT-IN: EDMP_CHAIN=1
-// (read at build time, like the other switches) - measured x1.00 against one launch per layer (profiles/r04_l2_chain.md), and a
-// persistent kernel is one more thing that can wait forever under co-tenancy; none on a GPU whose workgroup ids do not go round-robin
-// over the XCDs.
-static int chain_inst_of(const Op& op) {
-    const int cg = op.rc.Cout / 8;
-    if (op.branch != 0 || cg != 64 || op.rc_L != 2) return -1;
-    if (op.kind == OP_RCB) {
-        if (op.rc_form == 2) return op.rc.res_out ? CI_K5K2_RES : CI_K5K2;
-        if (op.rc_form == 0) return op.rc.res_out ? CI_K5_RES : CI_K5;
-        return -1;
-    }
-    if (op.kind == OP_WRS && op.wrs_kind == WK_UP) return CI_UP;
-    return -1;
-}
-static int find_chains(edmp_ctx* ctx, UNet* u) {
-    const char* on = getenv("EDMP_CHAIN");
-    if (!on || !on[0] || on[0] == '0') return EDMP_OK;
-    if (ctx->chain_ok < 0) {
-        bool ok = false;
-        if (int rc = probe_xcd_round_robin(ctx->stream, &ok)) return rc;
-        ctx->chain_ok = ok ? 1 : 0;
-    }
-    if (getenv("EDMP_CHAIN_DEBUG")) fprintf(stderr, "[edmp] workgroup ids round-robin over the XCDs: %s\n", ctx->chain_ok ? "yes" : "NO (layer chains off)");
-    if (!ctx->chain_ok) return EDMP_OK;
-    const int n = (int)u->prog.size();
-    for (int i = 0; i < n;) {
-        if (chain_inst_of(u->prog[i]) < 0) {
-            ++i;
-            continue;
-        }
-        UNet::ChainSeg seg{};
-        seg.first = i;
-        while (i < n && seg.n < kChainMaxOps && chain_inst_of(u->prog[i]) >= 0) seg.inst[seg.n++] = chain_inst_of(u->prog[i++]);
-        if (seg.n >= 2) u->chains.push_back(seg);
-    }
-    if (getenv("EDMP_CHAIN_DEBUG"))
-        for (auto& c : u->chains) fprintf(stderr, "[edmp] layer chain: ops %d..%d (%d layers in one launch)\n", c.first, c.first + c.n - 1, c.n);
-    if (!u->chains.empty()) {
-        u->chain_tiles = (u->max_batch + 31) / 32;
-        EDMP_HIP_CHECK(hipMalloc((void**)&u->chain_ctr, (size_t)kChainCtrWords * u->chain_tiles * sizeof(unsigned)));
-        EDMP_HIP_CHECK(hipMemset(u->chain_ctr, 0, (size_t)kChainCtrWords * u->chain_tiles * sizeof(unsigned)));
-        if (!ctx->chain_abort) EDMP_HIP_CHECK(hipHostMalloc((void**)&ctx->chain_abort, sizeof(int), hipHostMallocMapped));
-        *ctx->chain_abort = 0;
-    }
-    return EDMP_OK;
-}
-
 // builds the layer program + device weight image.  packed == nullptr: repack `params` (state-dict order) on the host;
 // otherwise `packed` IS the device image (edmp_unet_read_packed of the same architecture): only the layout is computed
 static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* params, int64_t n_params, int max_batch, const float* packed,
@@ -1516,7 +1456,6 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
         EDMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
     resolve_program(u, pl);
-    if (int rc = find_chains(ctx, u)) return rc;
     u->flops_nominal += pl.head_flops;
     u->flops_exec += pl.head_flops;
     u->flops_direct += pl.head_flops;
@@ -1590,40 +1529,9 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
         EDMP_HIP_CHECK(hipEventRecord(whole.a, main_stream));
     }
     auto coff = [&](auto* q) { return q ? q + unet_chain_offset(u, q, r0) : q; };
-    EDMP_REQUIRE(!(ctx->chain_abort && *ctx->chain_abort), "a persistent layer chain gave up waiting for its cluster (results of that run are invalid): rebuild the model with EDMP_NO_CHAIN=1");
-    // per-launch event brackets (prof 1) want one launch per op: chains are bypassed there
-    // ... and so are they for row chains of one batch (run_stream set): the L2-local hand-over of a layer chain is only safe while no other
-    // kernel of the process starts or ends on the GPU - with three or more other streams busy, stale activations were read (round 4)
-    const bool use_chains = !u->chains.empty() && pf.on != 1 && run_stream == nullptr;
-    size_t next_chain = 0;
-    int skip_until = -1;
     int op_index = -1;
     for (const Op& op : u->prog) {
         ++op_index;
-        if (op_index < skip_until) continue;
-        if (use_chains && next_chain < u->chains.size() && u->chains[next_chain].first == op_index) {
-            const UNet::ChainSeg& seg = u->chains[next_chain++];
-            ChainP a{};
-            for (int k = 0; k < seg.n; ++k) {
-                const Op& o = u->prog[seg.first + k];
-                RcbP q = o.rc;
-                q.B = B;
-                q.src1 = coff(q.src1), q.src2 = coff(q.src2), q.dst = coff(q.dst), q.add_res = coff(q.add_res), q.res_out = coff(q.res_out);
-                q.add_tb = (o.kind == OP_RCB && o.tb_off >= 0) ? trow + o.tb_off : nullptr;
-                EDMP_REQUIRE(q.C2 == 0 || q.C2 == q.C1, "layer chain: the two halves of a concatenated input must have the same width");
-                a.op[k] = q;
-                a.inst[k] = seg.inst[k];
-            }
-            a.n_ops = seg.n;
-            a.n_tiles = (B + 31) / 32;
-            // row chains of one batch (sampler.hip) run concurrently on their own rows: their clusters use their own counters
-            a.ctr = u->chain_ctr + (size_t)(r0 / 32) * kChainCtrWords;
-            a.abort_flag = ctx->chain_abort;
-            EDMP_REQUIRE(r0 % 32 == 0 && r0 / 32 + a.n_tiles <= u->chain_tiles, "layer chain: rows %d.. are not whole sample tiles of the model's batch", r0);
-            if (int rc = launch_l2_chain(a, main_stream)) return rc;
-            skip_until = seg.first + seg.n;
-            continue;
-        }
         hipStream_t s = main_stream;
         EDMP_REQUIRE(!(run_stream && op.branch), "the side-stream build of the layer program (EDMP_SIDE_STREAM) cannot run as row chains");
         if (op.branch == 1) {

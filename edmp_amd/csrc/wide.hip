@@ -173,17 +173,9 @@ struct WideAcc<16> {
     using type = __attribute__((ext_vector_type(4))) float;
 };
 
-// No gate: the stand-alone kernel.  A gate (chain.hip: the cluster barrier of a persistent layer chain) is called once in the
-// prologue, after everything that does not depend on other workgroups has been requested (weight fragments of chunk 0, epilogue
-// operands) and before the first activation load.
-struct WideNoGate {
-    static constexpr bool kGated = false;
-    __device__ __forceinline__ void operator()() const {}
-};
-
 // The work of one workgroup: tile (channel group `grp`, sample tile `tile`) of the conv `p`; `lds` = the workgroup's dynamic LDS.
-template <int KIND, int MS, int CG, int GS, int LIN, bool RES, class Gate>
-__device__ __forceinline__ void wide_conv_body(const RcbP& p, const int grp, const int tile, float* lds, Gate gate) {
+template <int KIND, int MS, int CG, int GS, int LIN, bool RES>
+__device__ __forceinline__ void wide_conv_body(const RcbP& p, const int grp, const int tile, float* lds) {
     using Cf = WideCfg<KIND, MS, CG, GS, LIN, RES>;
     using acc_t = typename WideAcc<MS>::type;
     constexpr int L = Cf::L, LLOAD = Cf::LLOAD, LOUT = Cf::LOUT, LACC = Cf::LACC, SW = Cf::SW, KG = Cf::KG, AR = Cf::AR;
@@ -304,19 +296,13 @@ __device__ __forceinline__ void wide_conv_body(const RcbP& p, const int grp, con
     // ---- prologue: weights of chunk 0 in flight, activation chunk 0 staged; chunks 1 and 2 are fetched and committed by the
     //      first K step, next to the fetch of chunk 3 (waiting for them here cost 1-2.5 us of every launch at L >= 4)
     f32x4 r1[NA];  // activation chunk 1 (the first step's extra staging set)
-    if constexpr (!Gate::kGated) load_a(0, raB);  // first: its data is on the way to the first MFMA twice (commit, barrier, fragment read) ...
+    load_a(0, raB);  // first: its data is on the way to the first MFMA twice (commit, barrier, fragment read) ...
     load_b(0, bA);   // ... the weights only once, and memory returns in request order
     // epilogue operands requested now (they land long before they are used; their pointers are not among the preloaded
     // kernel arguments, so anything earlier would put a scalar-memory wait in front of the loads above)
     const float bias_v = (ks == 0) ? p.bias[co0 + s * SW + (lane & (SW - 1))] : 0.0f;
     float rbias_v = 0.0f;
     if constexpr (RES) rbias_v = (ks == 0) ? p.res_bias[co0 + s * SW + (lane & (SW - 1))] : 0.0f;
-    if constexpr (Gate::kGated) {
-        // layer chain: weights and epilogue operands are in flight; now wait until the other workgroups of this sample tile's
-        // cluster have finished the previous layer, then fetch the activations they wrote
-        gate();
-        load_a(0, raB);
-    }
     commit_a(lds, raB);
     __syncthreads();
     EDMP_STAMP(0, 1)
@@ -709,7 +695,7 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(const float* a_src1, con
             tile = lin / ng;
         }
     }
-    wide_conv_body<KIND, MS, CG, GS, LIN, RES>(p, grp, tile, lds, WideNoGate{});
+    wide_conv_body<KIND, MS, CG, GS, LIN, RES>(p, grp, tile, lds);
 }
 
 // host: [tap][Cout][Cin] (taps 0..4; tap index 5 = the folded residual 1x1 conv) -> fragment stream

@@ -197,7 +197,8 @@ int edmp_sampler_set_graph(edmp_ctx* ctx, int on);
  * filled by another chain's launches.  Rows are independent except for the whole-batch sum(g^2) of a guided step
  * (lib/guide.py:629): every chain writes its rows' partial sums, waits (HIP events) until all chains have, and normalises by the
  * total formed in the single-chain summation order, so results are BIT-IDENTICAL to chains = 1 (Q7's NaN rule included).
- * Ignored (= 1) while an all-reduce hook, profiling brackets or hipGraph replay are active.  1 <= chains <= 16; default 1. */
+ * Ignored (= 1) while an all-reduce hook or profiling brackets are active.  chains > 1 takes precedence over hipGraph replay
+ * (edmp_sampler_set_graph / EDMP_GRAPH=1): such a call is enqueued eagerly, nothing is captured.  1 <= chains <= 16; default 1. */
 int edmp_sampler_set_chains(edmp_ctx* ctx, int chains);
 
 /* ---- training-side forward process --------------------------------------------------------- */

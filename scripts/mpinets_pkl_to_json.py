@@ -8,8 +8,8 @@ JSON problem-set file `edmp_amd.scenes.ProblemSetDataset` / `scenes.load_problem
 The pickles hold `mpinets.types.PlanningProblem` dataclasses (mpinets/types.py:35-46) whose obstacles are
 `geometrout.primitive.Cuboid` / `Cylinder` objects.  Neither geometrout nor robofin nor mpinets needs to be installed: a
 restricted `pickle.Unpickler` maps every class of those packages (and pyquaternion, which geometrout's SO3 wraps) to a light
-attribute record, lets NumPy's own reconstruction helpers through and refuses everything else - unpickling cannot run foreign
-code.  The converter then applies the reference loader's conversions (datasets/load_test_dataset.py):
+attribute record, lets an exact list of NumPy's array / scalar / dtype reconstruction helpers through (`_NUMPY_GLOBALS`; NOT
+`numpy.*`, which also holds `exec`-like helpers) and refuses every other global a pickle names.  The converter then applies the reference loader's conversions (datasets/load_test_dataset.py):
   * the three problem types of a scene type are concatenated task_oriented | neutral_start | neutral_goal (:53-56);
   * quaternions are stored scalar-FIRST in the pickles (`list(obstacle._pose._so3._quat)`, :108, :114) - kept as
     `quaternion_wxyz` in the JSON; the w-first -> w-last roll of :126 / :133 happens in `scenes.problem_to_arrays`;
@@ -70,20 +70,30 @@ def _stub(module: str, name: str):
     return _stub_cache[key]
 
 
+# the NumPy globals an ndarray / scalar / dtype pickle names (protocols 2-5, NumPy 1.x `numpy.core` and 2.x `numpy._core` spellings);
+# everything else under numpy.* is refused
+_NUMPY_GLOBALS = frozenset(
+    (mod, name)
+    for mod in ("numpy", "numpy.core.multiarray", "numpy._core.multiarray", "numpy.core.numeric", "numpy._core.numeric")
+    for name in ("_reconstruct", "scalar", "ndarray", "dtype", "_frombuffer")
+)
+
+
 class StubUnpickler(pickle.Unpickler):
-    """geometrout / mpinets / pyquaternion / robofin classes -> Record stubs; NumPy reconstruction helpers and plain builtins ->
-    the real things; anything else is refused."""
+    """geometrout / mpinets / pyquaternion / robofin classes -> Record stubs; NumPy's array / scalar / dtype reconstruction helpers (an exact
+    (module, name) list) and plain builtins -> the real things; anything else is refused."""
 
     def find_class(self, module, name):
         top = module.split(".")[0]
         if top in STUB_PACKAGES:
             return _stub(module, name)
-        if top == "numpy":
+        if (module, name) in _NUMPY_GLOBALS:  # exact pairs only: `numpy.*` as a whole holds callables that run code (numpy.testing..runstring)
             return super().find_class(module, name)
         if module == "builtins" and name in _SAFE_BUILTINS:
             return super().find_class(module, name)
         if (module, name) in (("collections", "OrderedDict"), ("collections", "defaultdict"), ("copyreg", "_reconstructor"), ("copy_reg", "_reconstructor"),
-                              ("dataclasses", "_HAS_DEFAULT_FACTORY_CLASS")):
+                              ("dataclasses", "_HAS_DEFAULT_FACTORY_CLASS"),
+                              ("_codecs", "encode")):  # (protocol-2 pickles carry an array's bytes as a latin-1 string)
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f"refusing to unpickle {module}.{name}: not a geometrout / mpinets / numpy type")
 

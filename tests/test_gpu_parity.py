@@ -1600,30 +1600,3 @@ def test_row_chains_small_and_ragged_batches(tiny_net):
     assert np.isnan(ref[:, :, 1:-1]).all() and np.array_equal(X, ref, equal_nan=True)
     with pytest.raises(Exception):
         dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], chains=17, **kw)
-
-
-def test_persistent_layer_chain_is_bit_identical(monkeypatch):
-    """VERDICT r3 item 7 (experiment, opt-in EDMP_CHAIN=1): the thirteen 512-channel L = 2 layers of the UNet as ONE persistent kernel
-    (csrc/chain.hip: the eight workgroups of a sample tile share an XCD; between layers a cluster barrier through that XCD's L2 instead
-    of a kernel boundary).  Same wide_conv_body on the same tiles: the forward must equal the launch-per-layer path bit for bit, for
-    whole and ragged batches, repeatedly (the cluster counters return to zero), and inside row chains of one batch."""
-    from edmp_amd import scenes
-    from edmp_amd.diffusion import Diffusion
-    from edmp_amd.temporalunet import TemporalUNet
-
-    plain = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, seed=1, max_batch=1024)
-    monkeypatch.setenv("EDMP_CHAIN", "1")
-    chained = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, seed=1, max_batch=1024)
-    monkeypatch.delenv("EDMP_CHAIN")
-    t = torch.tensor([77.0])
-    for B in (1024, 1000, 33, 5):
-        x = torch.randn(B, 7, 50, device=DEV)
-        ref = plain(x, t).cpu().numpy()
-        for _ in range(3):
-            assert np.array_equal(chained(x, t).cpu().numpy(), ref), B
-    dif = Diffusion(T, DEV)
-    noise = dif.ctx.to_dev(np.random.RandomState(4).standard_normal((T + 1, 256, 7, 50)), torch.float64)
-    kw = dict(batch_size=256, start=scenes.DEFAULT_START, goal=scenes.DEFAULT_GOAL, noise=noise, t_stop=T - 6)
-    ref = dif.denoise_guided(plain, None, 50, 7, None, **kw)
-    assert np.array_equal(dif.denoise_guided(chained, None, 50, 7, None, **kw), ref)
-    assert np.array_equal(dif.denoise_guided(chained, None, 50, 7, None, chains=2, **kw), ref)

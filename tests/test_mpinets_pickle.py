@@ -202,6 +202,31 @@ def test_unpickler_refuses_foreign_code(tmp_path):
         conv.load_pickle(pickle.dumps({"tabletop": {"task_oriented": [Evil()]}}))
 
 
+def test_unpickler_refuses_numpy_code_gadgets(tmp_path):
+    """`numpy.*` as a whole is not safe to resolve - numpy.testing._private.utils.runstring(code, dict) is `exec`.  Only
+    the exact reconstruction helpers of arrays / scalars / dtypes pass; real arrays of every pickle protocol still load."""
+    conv = _load_converter()
+    marker = tmp_path / "pwned"
+
+    class Gadget:
+        def __reduce__(self):
+            from numpy.testing._private.utils import runstring
+
+            return (runstring, (f"open({str(marker)!r}, 'w').write('x')", {}))
+
+    with pytest.raises(pickle.UnpicklingError):
+        conv.load_pickle(pickle.dumps({"tabletop": {"task_oriented": [Gadget()]}}))
+    assert not marker.exists()
+    for mod, name in (("numpy", "load"), ("numpy.lib.npyio", "load"), ("numpy.ctypeslib", "load_library"), ("numpy.f2py", "compile")):
+        blob = b"\x80\x02c" + mod.encode() + b"\n" + name.encode() + b"\n."  # protocol-2 GLOBAL opcode naming (mod, name)
+        with pytest.raises(pickle.UnpicklingError):
+            conv.load_pickle(blob)
+    payload = {"a": np.arange(12.0).reshape(3, 4), "s": np.float64(2.5), "i": np.int32(7), "f": np.asfortranarray(np.eye(3, dtype=np.float32))}
+    for proto in range(2, pickle.HIGHEST_PROTOCOL + 1):
+        back = conv.load_pickle(pickle.dumps(payload, protocol=proto))
+        assert np.array_equal(back["a"], payload["a"]) and back["s"] == 2.5 and back["i"] == 7 and np.array_equal(back["f"], payload["f"])
+
+
 def test_infer_serial_names_the_missing_converted_file(tmp_path):
     """a run config with the reference's dataset types ('global' | 'hybrid' | 'both', datasets/load_test_dataset.py:15-38) looks for the
     converted JSON next to where the pickle would be and says what to do when it is not there - before any GPU is touched"""
