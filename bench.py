@@ -41,9 +41,9 @@ def effective_cores() -> int:
 
 
 def pmc_traffic():
-    """HBM MB per conv-family launch from the committed rocprofv3 PMC passes (profiles/r04_pmc_hbm_traffic.json, else
+    """HBM MB per conv-family launch from the committed rocprofv3 PMC passes (profiles/r05_pmc_hbm_traffic.json, else
     an earlier round's; produced by scripts/pmc_unet_forward.py + scripts/summarize_pmc.py).  Counters cannot be read live."""
-    for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+    for name in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)["conv_family"]
@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true", help="skip the instrumented (HIP-event) pass")
     ap.add_argument("--cpu-steps", type=int, default=16, help="reverse steps of the bounded CPU-baseline sample")
     ap.add_argument("--no-two-scenes", action="store_true", help="skip the informative two-scenes-in-flight measurement")
+    ap.add_argument("--no-problem-set", action="store_true", help="skip the informative problem-set measurement (16 distinct scenes through infer_serial.run)")
     ap.add_argument("--chains", type=int, default=int(os.environ.get("EDMP_CHAINS", "1")),
                     help="run the one batch as this many row-sharded chains on separate HIP streams (edmp_sampler_set_chains; bit-identical results)")
     args = ap.parse_args()
@@ -342,6 +343,16 @@ def main():
                                        "note": "two independent 1024-row scenes on two contexts (streams) of this GPU, one host thread each; results bit-identical to the "
                                                "one-at-a-time runs; informative, not the named config (one batch of 1024)"}
         del net2, guide2, dif2, noise2
+
+    # ---- informative: a PROBLEM SET the way the reference counts a scene (never `value`) --------------------------------------
+    # The reference's per-scene clock (infer_serial.py:108-157) covers guide construction + IK-goal filter + sampling + best pick;
+    # the timed loop above builds the guide once.  infer_serial.run over 16 distinct synthetic scenes of this workload's size
+    # (true cylinders included, noise drawn per scene from NumPy's global RandomState), serial and with two scenes in flight.
+    if world == 1 and rank == 0 and not logical and not args.no_problem_set:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import problem_set_bench
+
+        out["problem_set"] = problem_set_bench.measure(16, B, tuple(guides), args.obstacles, min(3, args.obstacles), device=dev)
 
     # ---- roofline of the dominant kernel family (fp32-MFMA conv kernels of the UNet), N=1 only ----------------------
     # Two extra, instrumented calls with HIP events on the context's stream:

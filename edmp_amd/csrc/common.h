@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <map>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/edmp_hip.h"
@@ -84,6 +86,15 @@ struct edmp_ctx {
     edmp::Sampler* sampler = nullptr;
     edmp::Prof prof;
     uint64_t epoch = 0;  // bumped whenever device pointers / tables a captured hipGraph baked in may have changed
+    // recycled device blocks of the per-scene objects (guide tables, row arrays, scratch): hipFree waits for EVERY stream of the
+    // device, so with two scenes in flight each of the ~20 frees of a scene change stalled its host thread behind the other scene's
+    // queued loop (72 ms per scene, profiles/r05_problem_set.md).  Blocks go back here instead and are handed out again by capacity;
+    // everything is freed when the context is destroyed.  Callers only recycle blocks no enqueued work still reads (they
+    // synchronise the context's stream first: edmp_guide_slot).
+    std::multimap<size_t, void*> pool_free;
+    std::unordered_map<void*, size_t> pool_cap;
+    size_t pool_bytes = 0;
+    int* d_int = nullptr;  // one device int for small read-backs (edmp_argmin_dev)
 };
 
 namespace edmp {
@@ -92,7 +103,10 @@ void unet_destroy(UNet*);
 bool unet_complete(const UNet*);   // loaded: has a layer program
 bool guide_complete(const Guide*);  // scene tables and row arrays both set
 int prof_fold(edmp_ctx* ctx);  // unet.hip: read the pending event pairs into the per-op / total accumulators
-void guide_destroy(Guide*);
+void guide_destroy(edmp_ctx* ctx, Guide*);  // the device blocks go back to the context's pool
+int ctx_alloc(edmp_ctx* ctx, void** p, size_t bytes);  // guide.hip: from the context's block pool, else hipMalloc
+void ctx_release(edmp_ctx* ctx, void* p);               // back into the pool (hipFree only beyond the pool's byte cap)
+void ctx_pool_destroy(edmp_ctx* ctx);
 void sampler_destroy(Sampler*);
 
 // RAII-less helper: device allocation tracked by the owner

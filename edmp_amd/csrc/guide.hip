@@ -20,11 +20,52 @@ namespace edmp {
 
 bool guide_complete(const Guide* g) { return g && g->aabb && g->obb && g->row_class; }
 
-void guide_destroy(Guide* g) {
+// ---- the context's device block pool (common.h: edmp_ctx::pool_free) ----------------------------------------------------------
+// best fit by capacity with bounded slack, so that scene after scene of the same shape reuses the same blocks
+int ctx_alloc(edmp_ctx* ctx, void** p, size_t bytes) {
+    const size_t need = (std::max<size_t>(bytes, 1) + 255) / 256 * 256;
+    auto it = ctx->pool_free.lower_bound(need);
+    if (it != ctx->pool_free.end() && it->first <= 4 * need + 65536) {
+        *p = it->second;
+        ctx->pool_bytes -= it->first;
+        ctx->pool_free.erase(it);
+        return EDMP_OK;
+    }
+    *p = nullptr;
+    EDMP_HIP_CHECK(hipMalloc(p, need));
+    ctx->pool_cap[*p] = need;
+    return EDMP_OK;
+}
+void ctx_release(edmp_ctx* ctx, void* p) {
+    if (!p) return;
+    auto it = ctx->pool_cap.find(p);
+    if (it == ctx->pool_cap.end()) {  // not from the pool
+        (void)hipFree(p);
+        return;
+    }
+    constexpr size_t kPoolCapBytes = size_t(512) << 20;
+    if (ctx->pool_bytes + it->second > kPoolCapBytes) {
+        ctx->pool_cap.erase(it);
+        (void)hipFree(p);
+        return;
+    }
+    ctx->pool_free.insert({it->second, p});
+    ctx->pool_bytes += it->second;
+}
+void ctx_pool_destroy(edmp_ctx* ctx) {
+    for (auto& e : ctx->pool_free) (void)hipFree(e.second);
+    ctx->pool_free.clear();
+    ctx->pool_cap.clear();
+    ctx->pool_bytes = 0;
+    if (ctx->d_int) (void)hipFree(ctx->d_int);
+    ctx->d_int = nullptr;
+}
+
+void guide_destroy(edmp_ctx* ctx, Guide* g) {
     if (!g) return;
     for (void* p : {(void*)g->aabb, (void*)g->row_class, (void*)g->method, (void*)g->grad_norm, (void*)g->sched, (void*)g->graw,
                     (void*)g->rowsq, (void*)g->sumsq, (void*)g->startgoal, (void*)g->vol_rows, (void*)g->obb, (void*)g->kind, (void*)g->flags})
-        if (p) (void)hipFree(p);
+        ctx_release(ctx, p);
     delete g;
 }
 
@@ -123,24 +164,38 @@ __device__ __forceinline__ Vec3 corner_pos(const float R[3][3], const float o[3]
     return p;
 }
 
-template <int MODE, class TIn>
-__global__ __launch_bounds__(256) void guide_kernel(GuideArgs<TIn> a, RobotConst rc) {
-    __shared__ float s_obs[4][EDMP_MAX_OBSTACLES * 6];
+// SPLIT = 1: one wave per row, four rows per workgroup (every mode).  SPLIT = 4 (GM_GRAD, the 125 launches of a denoise_guided call;
+// round 5): a workgroup = ONE row, its four waves each take a group of links - {0,1,2}, {3,4}, {5,6}, {hand, finger} (balanced on
+// obstacle loop + corner search + chain rule + the DH prefix a group has to walk) - and the per-joint partial gradients are added in
+// the fixed order ((w0 + w1) + w2) + w3.  One wave per row is a latency-bound layout (1024 rows = one wave per SIMD, ~15 k dependent
+// VALU instructions each: 44.5 us per launch); with four waves per SIMD the same work is throughput-bound.  The link sum is
+// regrouped, so results differ from SPLIT = 1 by f32 rounding (same gates).
+template <int MODE, class TIn, int SPLIT = 1>
+__global__ __launch_bounds__(256, (SPLIT == 4 ? 4 : 1)) void guide_kernel(GuideArgs<TIn> a, RobotConst rc) {
+    static_assert(SPLIT == 1 || (SPLIT == 4 && MODE == GM_GRAD), "the link-split layout exists for the gradient only");
+    __shared__ float s_obs[SPLIT == 4 ? 1 : 4][EDMP_MAX_OBSTACLES * 6];
+    __shared__ float s_g[SPLIT == 4 ? 3 : 1][SPLIT == 4 ? 7 : 1][64];  // partial gradients of waves 1..3
     const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    const int r = a.row0 + blockIdx.x * 4 + wv;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = (SPLIT == 4) ? a.row0 + blockIdx.x : a.row0 + blockIdx.x * 4 + wv;
     const bool row_ok = r < a.n;
     const int rr = row_ok ? r : a.row0;
     const int L = a.L;
     const int no = a.no;
-    // obstacle AABBs of this row's class at step t -> LDS slice of this wave
+    // obstacle AABBs of this row's class at step t -> LDS slice of this wave (SPLIT = 4: one table for the row's four waves)
     {
         const int cls = a.use_row_class ? a.row_class[rr] : 0;
         const float* src = a.aabb + ((size_t)cls * (a.T + 1) + a.t) * no * 6;
-        for (int i = lane; i < no * 6; i += 64) s_obs[wv][i] = src[i];
+        if (SPLIT == 4) {
+            for (int i = threadIdx.x; i < no * 6; i += 256) s_obs[0][i] = src[i];
+        } else {
+            for (int i = lane; i < no * 6; i += 64) s_obs[wv][i] = src[i];
+        }
     }
     __syncthreads();
-    const float* obs = s_obs[wv];
+    const float* obs = s_obs[SPLIT == 4 ? 0 : wv];
+    // SPLIT = 4: this wave's links and the last joint frame it needs
+    const int my_jmax = (SPLIT == 4) ? (wv == 0 ? 2 : wv == 1 ? 4 : 6) : 6;
 
     bool sv;
     if (MODE == GM_IV_VOL) sv = false;
@@ -185,6 +240,7 @@ __global__ __launch_bounds__(256) void guide_kernel(GuideArgs<TIn> a, RobotConst
 
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
+        if (SPLIT == 4 && j > my_jmax) break;  // (wave-uniform)
         // T <- T * DH_j(q_j)                                                              lib/guide.py:45-72, 92
         {
             float sq, cq;
@@ -213,6 +269,7 @@ __global__ __launch_bounds__(256) void guide_kernel(GuideArgs<TIn> a, RobotConst
         for (int ll = 0; ll < 3; ++ll) {
             if (ll > 0 && j != 6) continue;
             const int l = (ll == 0) ? j : 6 + ll;
+            if (SPLIT == 4 && (l < 3 ? 0 : l < 5 ? 1 : l < 7 ? 2 : 3) != wv) continue;  // another wave's link (wave-uniform)
             // link transform = T * static_frame[l]                                          lib/guide.py:350
             float LR[3][3], Lo[3];
 #pragma unroll
@@ -348,6 +405,17 @@ __global__ __launch_bounds__(256) void guide_kernel(GuideArgs<TIn> a, RobotConst
     }
 
     if (MODE == GM_GRAD) {
+        if (SPLIT == 4) {
+            // partial gradients of the link groups -> wave 0, added in a fixed order
+            if (wv > 0) {
+#pragma unroll
+                for (int i = 0; i < 7; ++i) s_g[wv - 1][i][lane] = g[i];
+            }
+            __syncthreads();
+            if (wv > 0) return;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) g[i] = ((g[i] + s_g[0][i][lane]) + s_g[1][i][lane]) + s_g[2][i][lane];
+        }
         float sq = 0.f;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
@@ -428,17 +496,16 @@ __global__ void argmin_kernel(const float* __restrict__ v, int n, int* __restric
     if (lane == 0) out[0] = (bi == 0x7fffffff) ? 0 : bi;
 }
 
-static int ensure_scratch(Guide* g, int B, int L) {
+static int ensure_scratch(edmp_ctx* ctx, Guide* g, int B, int L) {
     if (g->scratch_B >= B && g->scratch_L >= L) return EDMP_OK;
-    for (void* p : {(void*)g->graw, (void*)g->rowsq, (void*)g->vol_rows})
-        if (p) (void)hipFree(p);
+    for (void* p : {(void*)g->graw, (void*)g->rowsq, (void*)g->vol_rows}) ctx_release(ctx, p);
     g->graw = nullptr;
     g->rowsq = nullptr;
     g->vol_rows = nullptr;
     int nb = std::max(B, g->scratch_B), nl = std::max(L, g->scratch_L);
-    EDMP_HIP_CHECK(hipMalloc((void**)&g->graw, (size_t)nb * 7 * nl * sizeof(float)));
-    EDMP_HIP_CHECK(hipMalloc((void**)&g->rowsq, (size_t)2 * nb * sizeof(double)));  // two buffers: row chains alternate between them per guided step
-    EDMP_HIP_CHECK(hipMalloc((void**)&g->vol_rows, (size_t)nb * sizeof(float)));
+    if (int rc = ctx_alloc(ctx, (void**)&g->graw, (size_t)nb * 7 * nl * sizeof(float))) return rc;
+    if (int rc = ctx_alloc(ctx, (void**)&g->rowsq, (size_t)2 * nb * sizeof(double))) return rc;  // two buffers: row chains alternate between them per guided step
+    if (int rc = ctx_alloc(ctx, (void**)&g->vol_rows, (size_t)nb * sizeof(float))) return rc;
     g->scratch_B = nb;
     g->scratch_L = nl;
     return EDMP_OK;
@@ -480,7 +547,17 @@ static int launch_guide(edmp_ctx* ctx, const TIn* joints, int ldw, int off, int 
     a.out = out;
     a.rowsq = rowsq;
     a.row0 = row0;
-    hipLaunchKernelGGL((guide_kernel<MODE, TIn>), dim3((n - row0 + 3) / 4), dim3(256), 0, run_stream ? run_stream : ctx->stream, a, g->rc);
+    hipStream_t st = run_stream ? run_stream : ctx->stream;
+    if constexpr (MODE == GM_GRAD) {
+        // EDMP_GUIDE_SPLIT=1: the one-wave-per-row layout for the gradient too (A/B runs)
+        static const bool split = [] { const char* e = getenv("EDMP_GUIDE_SPLIT"); return !(e && e[0] == '1'); }();
+        if (split) {
+            hipLaunchKernelGGL((guide_kernel<MODE, TIn, 4>), dim3(n - row0), dim3(256), 0, st, a, g->rc);
+            EDMP_HIP_CHECK(hipGetLastError());
+            return EDMP_OK;
+        }
+    }
+    hipLaunchKernelGGL((guide_kernel<MODE, TIn, 1>), dim3((n - row0 + 3) / 4), dim3(256), 0, st, a, g->rc);
     EDMP_HIP_CHECK(hipGetLastError());
     return EDMP_OK;
 }
@@ -490,7 +567,7 @@ int guide_prepare(edmp_ctx* ctx, int B, int L) {  // allocate the step scratch u
     Guide* g = ctx->guide;
     EDMP_REQUIRE(g, "scene/rows not set");
     const float* before = g->graw;
-    int rc = ensure_scratch(g, B, L);
+    int rc = ensure_scratch(ctx, g, B, L);
     if (g->graw != before) ctx->epoch++;
     return rc;
 }
@@ -505,7 +582,7 @@ int guide_raw_gradient_from_X(edmp_ctx* ctx, const double* X_dev, int B, int N, 
     EDMP_REQUIRE(t >= 0 && t <= g->T, "t out of range");
     EDMP_REQUIRE(0 <= r0 && r0 < r1 && r1 <= B && (buf == 0 || buf == 1), "bad row range %d..%d of %d", r0, r1, B);
     EDMP_REQUIRE(!(reduce && (r0 != 0 || r1 != B)), "the stand-alone reduction runs over the whole batch");
-    int rc = ensure_scratch(g, B, N - 2);
+    int rc = ensure_scratch(ctx, g, B, N - 2);
     if (rc) return rc;
     hipStream_t st = run_stream ? run_stream : ctx->stream;
     rc = launch_guide<GM_GRAD, double>(ctx, X_dev, N, 1, r1, N - 2, t, 1, 1, g->graw, g->rowsq + (size_t)buf * g->scratch_B, r0, st);
@@ -557,15 +634,17 @@ extern "C" int edmp_scene_set(edmp_ctx* ctx, const double* obstacle_config, int 
     ctx->epoch++;
     EDMP_REQUIRE(G >= 1 && T >= 1, "need at least one guide class and one step");
     EDMP_HIP_CHECK(hipSetDevice(ctx->device));
+    // (device blocks come from / go back to the context's pool and every copy is enqueued on the context's stream: no hipFree, no
+    // null-stream copy - a scene change on one context must not wait for another context's queued loop, see common.h)
     if (!ctx->guide) {
         ctx->guide = new Guide();
-        EDMP_HIP_CHECK(hipMalloc((void**)&ctx->guide->sumsq, sizeof(double)));
-        EDMP_HIP_CHECK(hipMalloc((void**)&ctx->guide->startgoal, 14 * sizeof(float)));
+        if (int rc = ctx_alloc(ctx, (void**)&ctx->guide->sumsq, sizeof(double))) return rc;
+        if (int rc = ctx_alloc(ctx, (void**)&ctx->guide->startgoal, 14 * sizeof(float))) return rc;
         EDMP_HIP_CHECK(hipMemsetAsync(ctx->guide->startgoal, 0, 14 * sizeof(float), ctx->stream));
     }
     Guide* g = ctx->guide;
     for (void** p : {(void**)&g->aabb, (void**)&g->obb, (void**)&g->kind}) {
-        if (*p) (void)hipFree(*p);
+        ctx_release(ctx, *p);
         *p = nullptr;
     }
     g->no = no;
@@ -598,29 +677,36 @@ extern "C" int edmp_scene_set(edmp_ctx* ctx, const double* obstacle_config, int 
             obb[o * 16 + 12 + k] = c[7 + k] / 2;  // the simulator's half extents (lib/environment.py:235)
         }
     }
-    EDMP_HIP_CHECK(hipMalloc((void**)&g->obb, obb.size() * sizeof(double)));
-    EDMP_HIP_CHECK(hipMalloc((void**)&g->kind, no * sizeof(int32_t)));
-    EDMP_HIP_CHECK(hipMemcpy(g->obb, obb.data(), obb.size() * sizeof(double), hipMemcpyHostToDevice));
-    EDMP_HIP_CHECK(hipMemset(g->kind, 0, no * sizeof(int32_t)));  // every obstacle a cuboid until edmp_scene_set_shapes says otherwise
-    double *d_sizes = nullptr, *d_clr = nullptr, *d_exp = nullptr;
-    float* d_tf = nullptr;
-    EDMP_HIP_CHECK(hipMalloc((void**)&d_sizes, sizes.size() * sizeof(double)));
-    EDMP_HIP_CHECK(hipMalloc((void**)&d_tf, tf.size() * sizeof(float)));
-    EDMP_HIP_CHECK(hipMalloc((void**)&d_clr, (size_t)G * T * sizeof(double)));
-    EDMP_HIP_CHECK(hipMalloc((void**)&d_exp, (size_t)G * T * sizeof(double)));
-    EDMP_HIP_CHECK(hipMalloc((void**)&g->aabb, (size_t)G * (T + 1) * no * 6 * sizeof(float)));
-    EDMP_HIP_CHECK(hipMemcpy(d_sizes, sizes.data(), sizes.size() * sizeof(double), hipMemcpyHostToDevice));
-    EDMP_HIP_CHECK(hipMemcpy(d_tf, tf.data(), tf.size() * sizeof(float), hipMemcpyHostToDevice));
-    EDMP_HIP_CHECK(hipMemcpy(d_clr, clearance, (size_t)G * T * sizeof(double), hipMemcpyHostToDevice));
-    EDMP_HIP_CHECK(hipMemcpy(d_exp, expansion, (size_t)G * T * sizeof(double), hipMemcpyHostToDevice));
-    int total = G * (T + 1) * no;
-    hipLaunchKernelGGL(obstacle_table_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, d_sizes, d_tf, d_clr, d_exp, g->aabb, G, T, no);
-    EDMP_HIP_CHECK(hipGetLastError());
-    EDMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    (void)hipFree(d_sizes);
-    (void)hipFree(d_tf);
-    (void)hipFree(d_clr);
-    (void)hipFree(d_exp);
+    if (int rc = ctx_alloc(ctx, (void**)&g->obb, obb.size() * sizeof(double))) return rc;
+    if (int rc = ctx_alloc(ctx, (void**)&g->kind, no * sizeof(int32_t))) return rc;
+    hipStream_t st = ctx->stream;
+    EDMP_HIP_CHECK(hipMemcpyAsync(g->obb, obb.data(), obb.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    EDMP_HIP_CHECK(hipMemsetAsync(g->kind, 0, no * sizeof(int32_t), st));  // every obstacle a cuboid until edmp_scene_set_shapes says otherwise
+    // one staging block for the table kernel's inputs: sizes | clearance | expansion (f64), then the transforms (f32)
+    const size_t n_sz = sizes.size(), n_gt = (size_t)G * T;
+    double* d_in = nullptr;
+    if (int rc = ctx_alloc(ctx, (void**)&d_in, (n_sz + 2 * n_gt) * sizeof(double) + tf.size() * sizeof(float))) return rc;
+    double *d_sizes = d_in, *d_clr = d_in + n_sz, *d_exp = d_clr + n_gt;
+    float* d_tf = reinterpret_cast<float*>(d_exp + n_gt);
+    int rc = ctx_alloc(ctx, (void**)&g->aabb, (size_t)G * (T + 1) * no * 6 * sizeof(float));
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = hipMemcpyAsync(d_sizes, sizes.data(), n_sz * sizeof(double), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_tf, tf.data(), tf.size() * sizeof(float), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_clr, clearance, n_gt * sizeof(double), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_exp, expansion, n_gt * sizeof(double), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            int total = G * (T + 1) * no;
+            hipLaunchKernelGGL(obstacle_table_kernel, dim3((total + 255) / 256), dim3(256), 0, st, d_sizes, d_tf, d_clr, d_exp, g->aabb, G, T, no);
+            e = hipGetLastError();
+        }
+        // the host vectors and the caller's arrays are read by the enqueued copies: complete them before returning
+        const hipError_t e2 = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = e2;
+    }
+    ctx_release(ctx, d_in);
+    if (rc) return rc;
+    EDMP_HIP_CHECK(e);
     return EDMP_OK;
 }
 
@@ -636,20 +722,23 @@ extern "C" int edmp_rows_set(edmp_ctx* ctx, const int32_t* row_class, const floa
         EDMP_REQUIRE(method[i] == 0.0f || method[i] == 1.0f, "row %d: guidance_method must be 0 (iv) or 1 (sv)", i);
     }
     EDMP_HIP_CHECK(hipSetDevice(ctx->device));
-    for (void* p : {(void*)g->row_class, (void*)g->method, (void*)g->grad_norm, (void*)g->sched})
-        if (p) (void)hipFree(p);
+    EDMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // nothing enqueued still reads the arrays that are replaced
+    for (void* p : {(void*)g->row_class, (void*)g->method, (void*)g->grad_norm, (void*)g->sched}) ctx_release(ctx, p);
     g->row_class = nullptr;
     g->method = nullptr;
     g->grad_norm = nullptr;
     g->sched = nullptr;
-    EDMP_HIP_CHECK(hipMalloc((void**)&g->row_class, B * sizeof(int32_t)));
-    EDMP_HIP_CHECK(hipMalloc((void**)&g->method, B * sizeof(float)));
-    EDMP_HIP_CHECK(hipMalloc((void**)&g->grad_norm, B * sizeof(double)));
-    EDMP_HIP_CHECK(hipMalloc((void**)&g->sched, (size_t)B * T * sizeof(double)));
-    EDMP_HIP_CHECK(hipMemcpy(g->row_class, row_class, B * sizeof(int32_t), hipMemcpyHostToDevice));
-    EDMP_HIP_CHECK(hipMemcpy(g->method, method, B * sizeof(float), hipMemcpyHostToDevice));
-    EDMP_HIP_CHECK(hipMemcpy(g->grad_norm, grad_norm, B * sizeof(double), hipMemcpyHostToDevice));
-    EDMP_HIP_CHECK(hipMemcpy(g->sched, sched, (size_t)B * T * sizeof(double), hipMemcpyHostToDevice));
+    if (int rc = ctx_alloc(ctx, (void**)&g->row_class, B * sizeof(int32_t))) return rc;
+    if (int rc = ctx_alloc(ctx, (void**)&g->method, B * sizeof(float))) return rc;
+    if (int rc = ctx_alloc(ctx, (void**)&g->grad_norm, B * sizeof(double))) return rc;
+    if (int rc = ctx_alloc(ctx, (void**)&g->sched, (size_t)B * T * sizeof(double))) return rc;
+    hipError_t e = hipMemcpyAsync(g->row_class, row_class, B * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(g->method, method, B * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(g->grad_norm, grad_norm, B * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(g->sched, sched, (size_t)B * T * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);  // the caller's arrays may go away after the call
+    EDMP_HIP_CHECK(e);
+    EDMP_HIP_CHECK(e2);
     g->B = B;
     g->rows_T = T;
     return EDMP_OK;
@@ -658,12 +747,11 @@ extern "C" int edmp_rows_set(edmp_ctx* ctx, const int32_t* row_class, const floa
 extern "C" int edmp_argmin_dev(edmp_ctx* ctx, const float* v_dev, int n, int* index_host) {
     EDMP_REQUIRE(ctx && v_dev && index_host && n >= 1, "edmp_argmin_dev: bad arguments");
     EDMP_HIP_CHECK(hipSetDevice(ctx->device));
-    int* d_idx = nullptr;
-    EDMP_HIP_CHECK(hipMalloc((void**)&d_idx, sizeof(int)));
+    if (!ctx->d_int) EDMP_HIP_CHECK(hipMalloc((void**)&ctx->d_int, sizeof(int)));  // kept for the life of the context
+    int* d_idx = ctx->d_int;
     hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(64), 0, ctx->stream, v_dev, n, d_idx);
     hipError_t e = hipMemcpyAsync(index_host, d_idx, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_idx);
     EDMP_HIP_CHECK(e);
     return EDMP_OK;
 }
@@ -672,8 +760,8 @@ extern "C" int edmp_scene_read_aabbs(edmp_ctx* ctx, int cls, int t, float* out_h
     EDMP_REQUIRE(ctx && ctx->guide && ctx->guide->aabb && out_host, "edmp_scene_read_aabbs: scene not set");
     Guide* g = ctx->guide;
     EDMP_REQUIRE(cls >= 0 && cls < g->G && t >= 0 && t <= g->T, "class/t out of range");
+    EDMP_HIP_CHECK(hipMemcpyAsync(out_host, g->aabb + ((size_t)cls * (g->T + 1) + t) * g->no * 6, (size_t)g->no * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     EDMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    EDMP_HIP_CHECK(hipMemcpy(out_host, g->aabb + ((size_t)cls * (g->T + 1) + t) * g->no * 6, (size_t)g->no * 6 * sizeof(float), hipMemcpyDeviceToHost));
     return EDMP_OK;
 }
 
@@ -713,7 +801,7 @@ extern "C" int edmp_guide_gradient_dev(edmp_ctx* ctx, const double* joints_dev, 
     EDMP_REQUIRE(joints_dev && grad_dev && start && goal, "null pointer");
     EDMP_REQUIRE(B == g->B, "batch %d != rows set (%d)", B, g->B);
     EDMP_HIP_CHECK(hipSetDevice(ctx->device));
-    rc = ensure_scratch(g, B, L);
+    rc = ensure_scratch(ctx, g, B, L);
     if (rc) return rc;
     rc = guide_set_startgoal(ctx, start, goal);
     if (rc) return rc;
@@ -734,7 +822,7 @@ extern "C" int edmp_row_swept_volumes_dev(edmp_ctx* ctx, const double* X_dev, in
     Guide* g = ctx->guide;
     EDMP_REQUIRE(X_dev && start && goal, "null pointer");
     EDMP_HIP_CHECK(hipSetDevice(ctx->device));
-    rc = ensure_scratch(g, B, N - 2);
+    rc = ensure_scratch(ctx, g, B, N - 2);
     if (rc) return rc;
     rc = guide_set_startgoal(ctx, start, goal);
     if (rc) return rc;

@@ -30,7 +30,13 @@
     X(2, WK_DOWN, 16, 32, 16, 13, false)  \
     X(3, WK_UP, 32, 64, 64, 2, false)     \
     X(4, WK_UP, 32, 32, 32, 4, false)     \
-    X(5, WK_UP, 16, 32, 16, 7, false)
+    X(5, WK_UP, 16, 32, 16, 7, false)     \
+    X(8, WK_K5, 16, 32, 32, 7, true)      \
+    X(9, WK_K5, 16, 32, 32, 7, false)     \
+    X(10, WK_DOWN, 16, 32, 32, 7, false)  \
+    X(11, WK_UP, 16, 32, 32, 4, false)    \
+    X(12, WK_DOWN, 16, 64, 64, 4, false)  \
+    X(13, WK_UP, 16, 64, 64, 2, false)
 
 // X(shard, MODE, C, L, SB, CIN)
 #define EDMP_LEVEL_INSTANCES(X)        \

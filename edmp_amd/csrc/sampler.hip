@@ -455,10 +455,11 @@ extern "C" void edmp_ctx_destroy(edmp_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     unet_destroy(ctx->unet);
-    guide_destroy(ctx->guide);
+    guide_destroy(ctx, ctx->guide);
     for (auto& e : ctx->unet_slots) unet_destroy(e.second);
-    for (auto& e : ctx->guide_slots) guide_destroy(e.second);
+    for (auto& e : ctx->guide_slots) guide_destroy(ctx, e.second);
     sampler_destroy(ctx->sampler);
+    ctx_pool_destroy(ctx);
     for (auto& e : ctx->prof.pending) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -519,7 +520,7 @@ extern "C" int edmp_guide_slot(edmp_ctx* ctx, uint64_t key) {
     if (!ctx) return EDMP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return EDMP_ERR_HIP;
     ctx->epoch++;
-    return select_slot(ctx->guide_slots, ctx->guide, ctx->guide_key, key, ctx->guide_cap, guide_destroy, guide_complete);
+    return select_slot(ctx->guide_slots, ctx->guide, ctx->guide_key, key, ctx->guide_cap, [ctx](Guide* g) { guide_destroy(ctx, g); }, guide_complete);
 }
 
 extern "C" int edmp_ctx_set_stream(edmp_ctx* ctx, void* hip_stream) {

@@ -296,8 +296,8 @@ extern "C" int edmp_scene_set_shapes(edmp_ctx* ctx, const int32_t* kind, int n_o
     EDMP_REQUIRE(kind && n_obstacles == g->no, "edmp_scene_set_shapes: need %d kinds (one per obstacle of the scene)", g->no);
     for (int i = 0; i < n_obstacles; ++i) EDMP_REQUIRE(kind[i] == 0 || kind[i] == 1, "obstacle %d: kind must be 0 (cuboid) or 1 (cylinder)", i);
     EDMP_HIP_CHECK(hipSetDevice(ctx->device));
+    EDMP_HIP_CHECK(hipMemcpyAsync(g->kind, kind, n_obstacles * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     EDMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    EDMP_HIP_CHECK(hipMemcpy(g->kind, kind, n_obstacles * sizeof(int32_t), hipMemcpyHostToDevice));
     return EDMP_OK;
 }
 
@@ -308,10 +308,10 @@ extern "C" int edmp_success_rows_dev(edmp_ctx* ctx, const double* X_dev, int B, 
     EDMP_REQUIRE(X_dev && B >= 1 && N >= 2 && substeps >= 1 && substeps <= 64, "edmp_success_rows_dev: need B >= 1, N >= 2, 1 <= substeps <= 64");
     EDMP_HIP_CHECK(hipSetDevice(ctx->device));
     if (g->flags_B < B) {
-        if (g->flags) (void)hipFree(g->flags);
+        ctx_release(ctx, g->flags);
         g->flags = nullptr;
         g->flags_B = 0;
-        EDMP_HIP_CHECK(hipMalloc((void**)&g->flags, ((size_t)3 * B + 4) * sizeof(int32_t)));
+        if (int rc = ctx_alloc(ctx, (void**)&g->flags, ((size_t)3 * B + 4) * sizeof(int32_t))) return rc;
         g->flags_B = B;
     }
     int32_t* ok = ok_dev ? ok_dev : g->flags;

@@ -130,6 +130,7 @@ struct Op {
     int lv_tb1, lv_tb2;  // offsets of the two blocks' time biases in the time-bias row
     int rc_L;     // OP_RCB / OP_WRS: input positions
     int rc_form;  // OP_RCB: 0 direct | 2 / 4 Karatsuba form at L = 2 / 4 (decided when the model was built)
+    int rc_ms;    // OP_RCB / OP_WRS: samples per workgroup (wide_ms, frozen at build time)
     int wrs_kind; // OP_WRS: WK_DOWN / WK_UP
     int tb_off;   // GN: offset into the time-bias row, -1 if none
     int branch;   // 0 = main stream; 1 = fork point (record before this op); 2 = runs on the side stream; 3 = join (wait) before this op
@@ -547,9 +548,6 @@ static int launch_gn(const GnP& p, hipStream_t s) {
     return EDMP_OK;
 }
 
-// position-tile kernel (wide.hip) instances: channels per GroupNorm group cg = Cout/8 and the input length select
-// the tile height MS (32 samples for cg >= 32, 16 for the 128-channel levels)
-static int wide_ms(int cout) { return cout / 8 >= 32 ? 32 : 16; }
 // Builder switches, read from the environment WHEN A MODEL IS BUILT (edmp_unet_load*) and frozen into its layer program:
 // two models built under different settings can live side by side in one process (A/B runs, the adversarial-weights test).
 // EDMP_NO_KARATSUBA=1: the L = 2 convolutions of the 512-channel levels in the direct form instead of the Karatsuba form
@@ -571,7 +569,34 @@ static int rcb_form(int cout, int L) {
     if (cg >= 32 && L == 4 && karatsuba_l4()) return 4;
     return 0;
 }
-static int launch_rcb(const RcbP& p, int L, int form, hipStream_t s) {
+// position-tile kernel (wide.hip) instances: the tile height MS = samples per workgroup.  16 for the 128-channel levels (32-sample
+// workgroups would leave half the CUs idle); 32 for the Karatsuba forms of the 256 / 512-channel levels (their weight stream per
+// FLOP doubles with 16-sample tiles: 16 TB/s out of the L2s at L = 4); and for the DIRECT-form instances of the 256 / 512-channel
+// levels - Conv1dBlock at L = 7, the k3s2 / ConvTranspose resamplers - 16 since round 5: 512 workgroups per launch, two co-resident per CU
+// (160 registers, 48 KB of LDS), one workgroup's prologue / epilogue / barriers run under the other's fp32 MFMAs (a wave's own VALU work
+// cannot: profiles/r05_coissue_control.md).  Same-stream A/B on isolated layer chains x1.06-1.08 (tools/dualbench.hip, profiles/r05_forkjoin.md).
+// EDMP_MS16=<mask> (read at model-build time, frozen into the layer program and the packed image's layout id) selects the families:
+// bit 0 Conv1dBlock L = 7 / 256 ch, bit 1 k3s2 L = 7 / 256 ch, bit 2 ConvTranspose L = 4 / 256 ch, bit 3 k3s2 L = 4 / 512 ch,
+// bit 4 ConvTranspose L = 2 / 512 ch.
+static const int kMs16Default = 0x00;
+static int ms16_mask() {
+    const char* e = getenv("EDMP_MS16");
+    return e ? (int)strtol(e, nullptr, 0) : kMs16Default;
+}
+// kind: WK_K5 (a Conv1dBlock; L = its length), WK_DOWN / WK_UP (L = input length)
+static int wide_ms(int cout, int L, int kind) {
+    const int cg = cout / 8;
+    if (cg < 32) return 16;
+    if (kind == WK_K5 && rcb_form(cout, L) != 0) return 32;
+    const int m = ms16_mask();
+    if (kind == WK_K5 && cg == 32 && L == 7) return (m & 1) ? 16 : 32;
+    if (kind == WK_DOWN && cg == 32 && L == 7) return (m & 2) ? 16 : 32;
+    if (kind == WK_UP && cg == 32 && L == 4) return (m & 4) ? 16 : 32;
+    if (kind == WK_DOWN && cg == 64 && L == 4) return (m & 8) ? 16 : 32;
+    if (kind == WK_UP && cg == 64 && L == 2) return (m & 16) ? 16 : 32;
+    return 32;
+}
+static int launch_rcb(const RcbP& p, int L, int form, int ms, hipStream_t s) {
     const int cg = p.Cout / 8;
     const bool res = p.res_out != nullptr;
 #define EDMP_K5(MS, CG, GS, LL) \
@@ -588,6 +613,7 @@ static int launch_rcb(const RcbP& p, int L, int form, hipStream_t s) {
         if (form == 4) return res ? launch_wide_t<WK_K5K4, 32, 32, 32, 4, true>(p, s) : launch_wide_t<WK_K5K4, 32, 32, 32, 4, false>(p, s);
         EDMP_K5(32, 32, 32, 4)
     }
+    if (cg == 32 && L == 7 && ms == 16) { EDMP_K5(16, 32, 32, 7) }
     if (cg == 32 && L == 7) { EDMP_K5(32, 32, 32, 7) }
     if (cg == 16 && L == 7) { EDMP_K5(16, 32, 16, 7) }
     if (cg == 16 && L == 13) { EDMP_K5(16, 32, 16, 13) }
@@ -659,8 +685,14 @@ static bool wrs_supported(int cout, int cin, int Lin, bool transposed) {
     if (transposed) return (cg == 64 && Lin == 2) || (cg == 32 && Lin == 4) || (cg == 16 && Lin == 7);
     return (cg == 64 && Lin == 4) || (cg == 32 && Lin == 7) || (cg == 16 && Lin == 13);
 }
-static int launch_wrs(const RcbP& p, int kind, int Lin, hipStream_t s) {
+static int launch_wrs(const RcbP& p, int kind, int Lin, int ms, hipStream_t s) {
     const int cg = p.Cout / 8;
+    if (ms == 16 && cg >= 32) {  // 16-sample tiles at 256 / 512 channels (wide_ms)
+        if (kind == WK_DOWN && cg == 32 && Lin == 7) return launch_wide_t<WK_DOWN, 16, 32, 32, 7, false>(p, s);
+        if (kind == WK_UP && cg == 32 && Lin == 4) return launch_wide_t<WK_UP, 16, 32, 32, 4, false>(p, s);
+        if (kind == WK_DOWN && cg == 64 && Lin == 4) return launch_wide_t<WK_DOWN, 16, 64, 64, 4, false>(p, s);
+        if (kind == WK_UP && cg == 64 && Lin == 2) return launch_wide_t<WK_UP, 16, 64, 64, 2, false>(p, s);
+    }
     if (kind == WK_DOWN) {
         if (cg == 64 && Lin == 4) return launch_wide_t<WK_DOWN, 32, 64, 64, 4, false>(p, s);
         if (cg == 32 && Lin == 7) return launch_wide_t<WK_DOWN, 32, 32, 32, 7, false>(p, s);
@@ -678,7 +710,7 @@ static int launch_wrs(const RcbP& p, int kind, int Lin, hipStream_t s) {
 // bench.py's per-kernel table be checked line by line against profiles/*_kernel_stats.csv
 static void op_kernel_name(const Op& op, char* out) {
     if (op.kind == OP_RCB || op.kind == OP_WRS) {
-        const int cg = op.rc.Cout / 8, ms = wide_ms(op.rc.Cout);
+        const int cg = op.rc.Cout / 8, ms = op.rc_ms;
         const int kind = op.kind == OP_RCB ? (op.rc_form == 2 ? 3 : op.rc_form == 4 ? 4 : 0) : op.wrs_kind;
         snprintf(out, 64, "wide_conv_kernel<%d, %d, %d, %d, %d, %s>", kind, ms, cg < 32 ? 32 : cg, cg, op.rc_L,
                  (op.kind == OP_RCB && op.rc.res_out) ? "true" : "false");
@@ -765,7 +797,7 @@ struct Packer {
     // Conv1d k5 weight (Cout, Cin, 5) [+ the block's residual 1x1 conv (Cout, Cin, 1)] -> the B-fragment stream of
     // wide_conv_kernel: [Cout/32][CinP/8][slots][64][4], slots = the taps that can be valid at length L (+ the residual)
     size_t conv_frag(const float* w, const float* wres, int cout, int cin, int cinp, int L) {
-        const int sw = wide_ms(cout);
+        const int sw = wide_ms(cout, L, WK_K5);
         const int kt0 = (L == 2) ? 1 : 0, ntap = (L == 2) ? 3 : 5, nslab = ntap + (wres ? 1 : 0);
         tag((L == 4 && sw == 32 && karatsuba_l4()) ? F_FRAG_K4 : (L == 2 && sw == 32 && cout / 8 == 64 && karatsuba_l2()) ? F_FRAG_K2 : F_FRAG);
         tag(cout), tag(cinp), tag(L), tag(wres ? 1 : 0), tag(sw);
@@ -790,18 +822,15 @@ struct Packer {
         return o;
     }
     // strided Conv1d k3 (Cout, Cin, 3) or ConvTranspose1d k4 (Cin, Cout, 4) of a wide level -> fragment stream, slot = tap
-    size_t resample_frag(const float* w, int cin, int cout, int k, bool transposed) {
-        tag(F_RESAMPLE), tag(cout), tag(cin), tag(k), tag(transposed ? 1 : 0);
-        if (dry) {
-            const int sw0 = wide_ms(cout);
-            return add((size_t)(cout / sw0) * (cin / (sw0 == 32 ? 8 : 16)) * k * 256);
-        }
+    size_t resample_frag(const float* w, int cin, int cout, int k, bool transposed, int Lin) {
+        const int sw = wide_ms(cout, Lin, transposed ? WK_UP : WK_DOWN);
+        tag(F_RESAMPLE), tag(cout), tag(cin), tag(k), tag(transposed ? 1 : 0), tag(sw);
+        if (dry) return add((size_t)(cout / sw) * (cin / (sw == 32 ? 8 : 16)) * k * 256);
         std::vector<float> tmp((size_t)6 * cout * cin, 0.0f);
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
                 for (int t = 0; t < k; ++t)
                     tmp[((size_t)t * cout + co) * cin + ci] = transposed ? w[((size_t)ci * cout + co) * k + t] : w[((size_t)co * cin + ci) * k + t];
-        const int sw = wide_ms(cout);
         size_t o = add((size_t)(cout / sw) * (cin / (sw == 32 ? 8 : 16)) * k * 256);
         pack_fragments(tmp.data(), cout, cin, 0, k, false, &host[o], sw);
         return o;
@@ -854,7 +883,7 @@ extern "C" int64_t edmp_unet_param_count(const edmp_unet_desc* desc) {
 // Version of the packing code: bump whenever the packing of any kernel family changes.  The layout id of an image is this
 // version mixed with the signature of the tensor sequence the builder actually produced (Packer::sig): a stale image, or
 // one written under other builder switches, fails to load instead of feeding a kernel the wrong fragment order.
-static const int kPackVersion = 300;
+static const int kPackVersion = 301;
 
 // ---- step 1 of a model build: the LAYER PLAN -----------------------------------------------------------------------------
 // An op of the plan: which kernel family, which activation buffers (ids of the pool) and which tensors of the packed weight image
@@ -1116,7 +1145,7 @@ struct LayerPlan {
             q[1] = pk.conv_frag(params + r1.cb[1].w.off, nullptr, Cc, Cc, Cc, Ll);
             q[2] = pk.conv_frag(params + r2.cb[0].w.off, nullptr, Cc, Cc, Cc, Ll);
             q[3] = pk.conv_frag(params + r2.cb[1].w.off, nullptr, Cc, Cc, Cc, Ll);
-            q[4] = pk.resample_frag(params + rs_w.off, Cc, Cc, mode == LV_DOWN ? 3 : 4, mode != LV_DOWN);
+            q[4] = pk.resample_frag(params + rs_w.off, Cc, Cc, mode == LV_DOWN ? 3 : 4, mode != LV_DOWN, Ll);
             q[5] = (mode == LV_UP_FINAL) ? pk.conv_frag(params + inv.final_cb.w.off, nullptr, Cc, Cc, Cc, 50) : 0;
             q[6] = pk.vec(params + r1.cb[0].b.off, Cc), q[7] = pk.vec(params + r1.cb[0].gw.off, Cc), q[8] = pk.vec(params + r1.cb[0].gb.off, Cc);
             q[9] = pk.vec(params + r1.rb.off, Cc);
@@ -1180,7 +1209,7 @@ struct LayerPlan {
             if (i != nd - 1) {
                 int Lout = (b.L - 1) / 2 + 1;
                 if (sw.fused && wrs_supported(dm[i + 1], b.C, b.L, false)) {
-                    size_t w = pk.resample_frag(params + inv.down_w[i].off, dm[i + 1], dm[i + 1], 3, false);
+                    size_t w = pk.resample_frag(params + inv.down_w[i].off, dm[i + 1], dm[i + 1], 3, false, b.L);
                     size_t bb = pk.vec(params + inv.down_b[i].off, dm[i + 1]);
                     x = emit_wrs(b, w, bb, dm[i + 1], WK_DOWN, 3, Lout);
                 } else {
@@ -1233,7 +1262,7 @@ struct LayerPlan {
             int Lout = 2 * b.L;
             if (Lout == 8 || Lout == 14 || Lout == 26) Lout -= 1;  // crop rule, temporalunet.py:70-71
             if (sw.fused && wrs_supported(dm[i - 1], b.C, b.L, true)) {
-                size_t w = pk.resample_frag(params + inv.up_w[j].off, dm[i - 1], dm[i - 1], 4, true);
+                size_t w = pk.resample_frag(params + inv.up_w[j].off, dm[i - 1], dm[i - 1], 4, true, b.L);
                 size_t bb = pk.vec(params + inv.up_b[j].off, dm[i - 1]);
                 x = emit_wrs(b, w, bb, dm[i - 1], WK_UP, 4, Lout);
             } else {
@@ -1340,6 +1369,7 @@ static void resolve_program(UNet* u, const LayerPlan& pl) {
             c.Cout = o.Cout;
             op.rc_L = o.Lin;
             op.wrs_kind = o.blk;
+            op.rc_ms = wide_ms(o.Cout, o.Lin, o.blk);
             op.flops_nominal = o.fn;
             op.flops_exec = o.fe;
             u->flops_nominal += o.fn;
@@ -1364,6 +1394,7 @@ static void resolve_program(UNet* u, const LayerPlan& pl) {
             c.Cout = o.Cout;
             op.rc_L = o.Lin;
             op.rc_form = rcb_form(o.Cout, o.Lin);
+            op.rc_ms = wide_ms(o.Cout, o.Lin, WK_K5);
             op.tb_off = o.tb_off;
             op.flops_nominal = o.fn;
             op.flops_exec = o.fe;
@@ -1562,7 +1593,7 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
             p.src1 = coff(p.src1), p.src2 = coff(p.src2), p.dst = coff(p.dst), p.add_res = coff(p.add_res), p.res_out = coff(p.res_out);
             p.add_tb = op.tb_off >= 0 ? trow + op.tb_off : nullptr;
             EDMP_REQUIRE(!(p.add_tb && p.add_res), "fused conv block: a launch adds the time bias (conv1) or the residual (conv2), not both");
-            rc = launch_rcb(p, op.rc_L, op.rc_form, s);
+            rc = launch_rcb(p, op.rc_L, op.rc_form, op.rc_ms, s);
         } else if (op.kind == OP_LVL) {
             LevelP p = op.lv;
             p.B = B;
@@ -1582,7 +1613,7 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
             RcbP p = op.rc;
             p.B = B;
             p.src1 = coff(p.src1), p.dst = coff(p.dst);
-            rc = launch_wrs(p, op.wrs_kind, op.rc_L, s);
+            rc = launch_wrs(p, op.wrs_kind, op.rc_L, op.rc_ms, s);
         } else if (op.kind == OP_CONV) {
             ConvP p = op.cv;
             p.B = B;

@@ -55,16 +55,24 @@ def end_effector_positions(trajectory):
     joints followed by the fixed rows d = 0.107, theta = -pi/4, d = 0.1034 (0.21 m beyond the joint-7 frame).
     float64 here, float32 in the reference: agrees to ~1e-7 m (pinned by tests/golden/g13_metrics.npz)."""
     tr = np.asarray(trajectory, dtype=np.float64)
-    pts = []
-    for i in range(tr.shape[1]):
-        T = np.eye(4)
-        for j in range(7):
-            a, d, al = franka.DH_A_D_ALPHA[j]
-            T = T @ _dh(a, d, al, tr[j, i])
-        for a, d, al, th in EE_STATIC_DH:
-            T = T @ _dh(a, d, al, th)
-        pts.append(T[:3, 3])
-    return np.array(pts)
+    n = tr.shape[1]
+
+    def dh_stack(a, d, alpha, q):  # (N, 4, 4): _dh for every waypoint at once (a per-waypoint Python loop cost 2 ms per call)
+        cq, sq, ca, sa = np.cos(q), np.sin(q), np.cos(alpha), np.sin(alpha)
+        D = np.zeros((n, 4, 4))
+        D[:, 0, 0], D[:, 0, 1], D[:, 0, 3] = cq, -sq, a
+        D[:, 1, 0], D[:, 1, 1], D[:, 1, 2], D[:, 1, 3] = sq * ca, cq * ca, -sa, -sa * d
+        D[:, 2, 0], D[:, 2, 1], D[:, 2, 2], D[:, 2, 3] = sq * sa, cq * sa, ca, ca * d
+        D[:, 3, 3] = 1.0
+        return D
+
+    T = np.broadcast_to(np.eye(4), (n, 4, 4))
+    for j in range(7):
+        a, d, al = franka.DH_A_D_ALPHA[j]
+        T = T @ dh_stack(a, d, al, tr[j])
+    for a, d, al, th in EE_STATIC_DH:
+        T = T @ _dh(a, d, al, th)
+    return np.ascontiguousarray(T[:, :3, 3])
 
 
 def path_lengths(trajectory) -> dict:

@@ -15,15 +15,21 @@ def row_classes(clearance: np.ndarray, expansion: np.ndarray):
     """Rows with identical (clearance[t], expansion[t]) schedules share one obstacle table: returns
     (row_class (B,) int32, class_clearance (G,T), class_expansion (G,T))."""
     B = clearance.shape[0]
+    # a guide owns a contiguous block of rows (infer_serial.py:56-91), so consecutive rows are nearly always equal: compare every
+    # row with its predecessor in one vectorised pass and key only the first row of each run (a Python loop over 1024 rows with two
+    # tobytes() each cost 1.5 ms per scene - the guide object is rebuilt for every scene, infer_serial.py:112)
+    key = np.ascontiguousarray(np.concatenate([clearance, expansion], axis=1)).view(np.uint64)  # bit patterns: -0.0 != 0.0, NaN == NaN
+    starts = np.concatenate([[0], 1 + np.flatnonzero(np.any(key[1:] != key[:-1], axis=1))]) if B > 1 else np.array([0])
     keys = {}
-    rc = np.zeros(B, dtype=np.int32)
     reps = []
-    for b in range(B):
-        k = (clearance[b].tobytes(), expansion[b].tobytes())
+    cls_of_run = np.empty(len(starts), dtype=np.int32)
+    for j, b in enumerate(starts):
+        k = key[b].tobytes()
         if k not in keys:
             keys[k] = len(reps)
-            reps.append(b)
-        rc[b] = keys[k]
+            reps.append(int(b))
+        cls_of_run[j] = keys[k]
+    rc = np.repeat(cls_of_run, np.diff(np.concatenate([starts, [B]]))).astype(np.int32)
     return rc, np.ascontiguousarray(clearance[reps], dtype=np.float64), np.ascontiguousarray(expansion[reps], dtype=np.float64)
 
 

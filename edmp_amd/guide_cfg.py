@@ -146,4 +146,8 @@ def guide_cfgs_from_run_cfg(run_cfg: dict, base_dir: str = ".") -> dict:
     if gpath is not None and not os.path.isabs(gpath):
         gpath = os.path.join(base_dir, gpath)
     dicts = [load_guide_dict(int(n), gpath) for n in run_cfg["guide"]["guides"]]
-    return build_guide_cfgs(dicts, run_cfg["guide"]["batch_size_per_guide"], int(run_cfg["model"]["T"]))
+    # extension (not in the reference's schema, which only allows B = G * batch_size_per_guide): `total_rows: 1024` deals that many
+    # rows to the guides as contiguous blocks (split_rows) - BASELINE.json's "batch=1024, 6-guide ensemble"
+    total = run_cfg["guide"].get("total_rows")
+    rows = split_rows(int(total), len(dicts)) if total else None
+    return build_guide_cfgs(dicts, run_cfg["guide"]["batch_size_per_guide"], int(run_cfg["model"]["T"]), rows_per_guide=rows)

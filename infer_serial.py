@@ -45,6 +45,57 @@ def _ranks(device):
     return dist.get_rank(), dist.get_world_size(), f"cuda:{index}"
 
 
+class _NoiseFeeder:
+    """Scenes in flight: every scene's (T+1, B, C, N) noise stream, drawn IN SCENE ORDER from the global NumPy RandomState (so each
+    scene sees the numbers the serial loop would give it) by ONE background thread into page-locked whole-scene buffers, ahead of the
+    scene that consumes it; the planning threads upload their buffer by DMA.  Drawing on the calling thread instead serialised the
+    loop on the host: 0.16 s of draws + a pageable 734 MB upload per 1024-row scene made two scenes in flight SLOWER than the serial
+    loop (profiles/r05_problem_set.md).  Exactly `n_scenes` streams are drawn: the global state ends where the serial loop leaves it."""
+
+    def __init__(self, ctx, n_scenes, shape, n_buffers):
+        import queue
+        import threading
+
+        from edmp_amd import nprng
+
+        n = int(np.prod(shape))
+        cache = getattr(ctx, "_scene_noise_buffers", None)
+        if cache is None or len(cache) < n_buffers or cache[0].numel() != n:
+            cache = ctx._scene_noise_buffers = [torch.empty(n, dtype=torch.float64, pin_memory=True) for _ in range(n_buffers)]
+        self.shape, self.free, self.ready = tuple(shape), queue.Queue(), queue.Queue()
+        for b in cache[:n_buffers]:
+            self.free.put(b)
+        nthr = nprng.draw_threads()
+
+        def work():
+            try:
+                for _ in range(n_scenes):
+                    b = self.free.get()
+                    if b is None:
+                        return
+                    nprng.standard_normal((n,), nthreads=nthr, out=b.numpy())
+                    self.ready.put(b)
+            except BaseException as exc:  # surfaced by next()
+                self.ready.put(exc)
+
+        self.thread = threading.Thread(target=work, name="edmp-scene-noise", daemon=True)
+        self.thread.start()
+
+    def next(self):
+        """the next scene's stream (scene order): a pinned (T+1, B, C, N) f64 tensor; blocks until it is drawn"""
+        b = self.ready.get()
+        if isinstance(b, BaseException):
+            raise b
+        return b.view(self.shape)
+
+    def recycle(self, t):
+        self.free.put(t.view(-1))
+
+    def close(self):
+        self.free.put(None)
+        self.thread.join()
+
+
 def job_summary(results, world=1):
     """This rank's tallies; under a launcher the sum over all ranks (all_gather_object of five small integers per rank - the
     trajectories stay where they were planned).  Keys: scenes, success_proxy (the reference's tally), success_strict, rows_collision_free, rows."""
@@ -75,9 +126,9 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=
     calling thread and each scene's noise is drawn there from the global NumPy RandomState, in the order the serial loop draws it."""
     from concurrent.futures import ThreadPoolExecutor
 
-    from edmp_amd.diffusion import draw_noise
     from edmp_amd.runtime import get_context, lane_context
 
+    t_enter = time.time()
     benchmark_cfg = GC.load_yaml(cfg_path)
     rank, world, device = _ranks(benchmark_cfg["model"]["device"]) if shard_scenes else (0, 1, benchmark_cfg["model"]["device"])
     traj_len = benchmark_cfg["model"]["traj_len"]
@@ -116,28 +167,43 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=
 
     def plan(lane, guide, start_joints, goal_joints, noise, meta, t0):
         diffuser, denoiser = lanes[lane]
+        tm = dict(meta.pop("timings"))
+        pinned = None
+        if noise is not None:  # scenes in flight: this scene's stream, drawn ahead by the feeder; one DMA, then the buffer goes back
+            t_w = time.time()
+            pinned = noise if isinstance(noise, torch.Tensor) else noise.result()
+            tm["noise_wait_s"] = time.time() - t_w
+            noise = diffuser.ctx.to_dev(pinned, torch.float64)
+        ta = time.time()
         trajectories = diffuser.denoise_guided(model=denoiser, guide=guide, batch_size=total_batch_size, traj_len=traj_len,
                                                num_channels=num_channels, condition=True, benchmarking=True, start=start_joints,
                                                goal=goal_joints, guidance_schedule=guide_cfgs["guidance_schedule"], noise=noise)
+        tb = time.time()
+        if pinned is not None:
+            feeder.recycle(pinned)  # (denoise_guided returned host trajectories: the upload out of the buffer is long done)
         vols, idx = guide.row_swept_volumes(start_joints, goal_joints, trajectories)
         trajectory = trajectories[idx]
         t_plan = time.time() - t0
+        tm["denoise_s"], tm["best_trajectory_s"] = tb - ta, time.time() - tb
         # success: pybullet execution (lib/environment.py:632-680) is unavailable -> exact link-box vs cuboid / cylinder
         # check along the interpolated trajectory, for EVERY row of the batch in one kernel (csrc/success.hip); the
         # scene's success is the chosen row's flag (infer_serial.py:165-168) under the reference's rule - no contact;
         # leaving the joint limits only prints there (lib/environment.py:659-661, 672) -, the stricter flag (also inside the
         # limits) and the batch rates are reported next to it, as is the guide's own (conservative, AABB) criterion
+        tc = time.time()
         chk = guide.success_rows(trajectories)
-        return dict(**meta, best_row=int(idx), swept_volume=float(vols[idx]), success_proxy=int(chk["collision_free"][idx]), success_strict=int(chk["ok"][idx]),
+        tm["success_check_s"] = time.time() - tc
+        return dict(**meta, timings=tm, best_row=int(idx), swept_volume=float(vols[idx]), success_proxy=int(chk["collision_free"][idx]), success_strict=int(chk["ok"][idx]),
                     rows_collision_free=chk["rows_collision_free"], rows_ok=chk["rows_ok"], rows=chk["rows"],
                     aabb_volume_zero=bool(ED.geometric_success(float(vols[idx]), trajectory)), first_collision_waypoint=int(chk["first"][idx]),
-                    path_length=EV.path_lengths(trajectory), sparc=EV.smoothness(trajectory), planning_time_s=t_plan, trajectory=trajectory)
+                    path_length=EV.path_lengths(trajectory), sparc=EV.smoothness(trajectory), planning_time_s=t_plan, scene_wall_s=time.time() - t0, trajectory=trajectory)
 
     t_success, t_strict, i, results, pending = 0, 0, 0, [], []
 
     def collect(fut):
         nonlocal t_success, t_strict
         r = fut.result() if hasattr(fut, "result") else fut
+        r["done_at"] = time.time()
         results.append(r)
         t_success += r["success_proxy"]  # the reference's tally: collision-free (infer_serial.py:165-168 on lib/environment.py:672)
         t_strict += r["success_strict"]
@@ -146,14 +212,20 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=
                   f"{r['swept_volume']:.4g}, geometric success (proxy, collision-free) {r['success_proxy']} ({r['rows_collision_free']}/{r['rows']} rows of the batch); "
                   f"also within the joint limits {r['success_strict']} ({r['rows_ok']}/{r['rows']})   running {t_success}/{len(results)} (strict {t_strict}/{len(results)})")
 
-    with ThreadPoolExecutor(max_workers=k) as pool:
-        for scene_type in benchmark_cfg["dataset"]["scene_types"]:
-            for scene_num in range(dataset.data_nums[scene_type]):
-                if max_scenes is not None and i >= max_scenes:
-                    break
-                if i % world != rank:  # another rank's scene
-                    i += 1
-                    continue
+    # this rank's scenes, in the cfg's order (scene i of that order belongs to rank i mod world)
+    mine = []
+    for scene_type in benchmark_cfg["dataset"]["scene_types"]:
+        for scene_num in range(dataset.data_nums[scene_type]):
+            if max_scenes is not None and i >= max_scenes:
+                break
+            if i % world == rank:
+                mine.append((i, scene_type, scene_num))
+            i += 1
+    feeder = _NoiseFeeder(base, len(mine), (T + 1, total_batch_size, num_channels, traj_len), k + 1) if (k > 1 and mine) else None
+    run.last_setup_s = time.time() - t_enter  # config, dataset, model load / upload: per run, not per scene
+    try:
+        with ThreadPoolExecutor(max_workers=k) as pool:
+            for i, scene_type, scene_num in mine:
                 lane = (i // world) % k
                 while len(pending) >= k:  # the lane's previous scene (and every earlier one) is done before its context is reused
                     collect(pending.pop(0))
@@ -164,22 +236,27 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=
                 kinds = np.concatenate([np.zeros(int(num_cuboids), dtype=np.int32), np.ones(int(num_cylinders), dtype=np.int32)])
                 guide = IntersectionVolumeGuide(obstacle_config=obstacle_config, device=lanes[lane][0].ctx, guide_cfgs=guide_cfgs, batch_size=total_batch_size,
                                                 obstacle_kinds=kinds)
+                t1 = time.time()
                 # IK-goal filter                                                              infer_serial.py:117-129
                 volumes = guide.cost(torch.tensor(all_ik_goals.reshape((-1, 7, 1))), 0, batch_size=all_ik_goals.shape[0]).sum(axis=(1, 2)).cpu().numpy()
                 indices = np.argsort(volumes)
                 goal_joints = all_ik_goals[indices][volumes[indices] < np.min(volumes) + 0.0008]
                 goal_joints = goal_joints[np.argmin(np.linalg.norm(start_joints - goal_joints, axis=1))]
+                t2 = time.time()
                 # serial loop: the sampler draws from the global RandomState while the GPU works (noise=None); several scenes in
-                # flight: this scene's whole stream is drawn here, in scene order, so every scene sees the numbers it would see serially
-                noise = None if k == 1 else draw_noise(T, total_batch_size, num_channels, traj_len)
-                meta = dict(scene_type=scene_type, scene_num=scene_num)
+                # flight: the feeder thread draws every scene's whole stream in scene order, so every scene sees the numbers it would
+                # see serially.  (pool.submit hands the scenes to the lanes in order, the feeder hands the streams out in the same order)
+                # where a scene's "Planning Time" (infer_serial.py:108-157: guide construction + IK filter + sampling + best pick) goes
+                meta = dict(scene_type=scene_type, scene_num=scene_num, timings=dict(guide_ctor_s=t1 - t0, ik_filter_s=t2 - t1))
                 if k == 1:
-                    collect(plan(lane, guide, start_joints, goal_joints, noise, meta, t0))  # serial: the reference's order of events
+                    collect(plan(lane, guide, start_joints, goal_joints, None, meta, t0))  # serial: the reference's order of events
                 else:
-                    pending.append(pool.submit(plan, lane, guide, start_joints, goal_joints, noise, meta, t0))
-                i += 1
-        while pending:
-            collect(pending.pop(0))
+                    pending.append(pool.submit(plan, lane, guide, start_joints, goal_joints, feeder.next(), meta, t0))
+            while pending:
+                collect(pending.pop(0))
+    finally:
+        if feeder is not None:
+            feeder.close()
     if world > 1 or verbose:
         summary = job_summary(results, world)
         if verbose and rank == 0:

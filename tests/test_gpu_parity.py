@@ -151,6 +151,38 @@ def test_fused_and_unfused_paths_agree(monkeypatch):
         assert rmse(a, b) <= 1e-5, (env, rmse(a, b))
 
 
+def test_sixteen_sample_tiles_of_the_direct_form_instances(monkeypatch):
+    """Round 5: the direct-form position-tile instances of the 256 / 512-channel levels (Conv1dBlock at L = 7, the k3s2 / ConvTranspose
+    resamplers) exist with 16-sample tiles (v_mfma_f32_16x16x4_f32, two workgroups per CU) beside the 32-sample ones; EDMP_MS16=<mask>
+    picks per family at model-build time (unet.hip: wide_ms).  Same arithmetic, another summation order: every mask gives the network
+    of the oracle within the gates of test_unet_golden, whole and ragged batches, and the families all differ from mask 0 only by rounding."""
+    from edmp_amd import weights as W
+    from edmp_amd.temporalunet import TemporalUNet
+    from oracle import edmp_oracle as O
+
+    sd = W.init_state_dict(12, 7, 32, FULL_DIMS)
+    x = torch.tensor(np.random.RandomState(4).standard_normal((70, 7, 50)), dtype=torch.float32)
+    t = torch.tensor([9.0])
+    ref = O.UNetOracle(sd)(x, t).numpy()
+    outs = {}
+    for mask in ("0x00", "0x01", "0x04", "0x1f"):
+        monkeypatch.setenv("EDMP_MS16", mask)
+        net = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, state_dict=sd, max_batch=70)
+        monkeypatch.delenv("EDMP_MS16")
+        y = net(x, t).cpu().numpy()
+        names = {n for n, _, _, _ in net.ctx.prof_ops()}  # the bound model's layer program
+        y33 = net(x[:33], t).cpu().numpy()
+        assert np.array_equal(y33, y[:33]), mask  # rows are independent of the batch they sit in
+        assert rmse(y, ref) <= 2e-5 and maxabs(y, ref) <= 2e-4, (mask, rmse(y, ref), maxabs(y, ref))
+        outs[mask] = (y, names)
+    for mask in ("0x01", "0x04", "0x1f"):
+        assert rmse(outs[mask][0], outs["0x00"][0]) <= 1e-5, mask
+    n0, n31 = outs["0x00"][1], outs["0x1f"][1]
+    if n0 and n31:  # the layer program really switched instances
+        assert "wide_conv_kernel<0, 32, 32, 32, 7, false>" in n0 and "wide_conv_kernel<0, 16, 32, 32, 7, false>" in n31
+        assert "wide_conv_kernel<2, 16, 64, 64, 2, false>" in n31 and "wide_conv_kernel<1, 16, 64, 64, 4, false>" in n31
+
+
 def test_obstacle_table(golden):
     from edmp_amd.guide import IntersectionVolumeGuide
 
@@ -1273,6 +1305,61 @@ def test_bench_plain_launch_with_gpus_2_spawns_two_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["config"]["global_batch"] == 2048
     assert d["dist_backend"] == ("gloo" if few else "nccl")
+
+
+def test_eight_ranks_shake_out_on_this_box(tmp_path):
+    """the driver's N = 8 launch, before the first 8-GPU lease - `python bench.py --gpus 8` (re-exec under the
+    launcher) and `torch.distributed.run --nproc-per-node 8 infer_serial.py --max-scenes 16` with EIGHT processes (gloo over the one
+    GPU of a test box: 8 contexts x 120 MB of weights; RCCL when eight GPUs are visible): ports, rendezvous, per-rank memory, the
+    summed world size and the scene deal.  Reference launch model: one process per device (benchmark/cfgs/cfg2.yaml:2,14)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    import yaml
+
+    from tests.conftest import ROOT
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    few = torch.cuda.device_count() < 8
+    if few:
+        env["EDMP_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--batch", "64", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["n_ranks_seen"] == 8 and d["config"]["global_batch"] == 512 and d["success_proxy"]["rows"] == 512
+    assert d["dist_backend"] == ("gloo" if few else "nccl") and np.isfinite(d["value"]) and d["value"] > 0
+    assert 0 <= d["best"]["rank"] < 8
+
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "cfg_c1_plumbing.yaml")))
+    cfg["dataset"]["scene_types"] = ["tabletop", "stress"]
+    cfg["dataset"]["num_scenes_per_type"] = 9  # 18 scenes in the cfg, --max-scenes stops at 16
+    os.makedirs(tmp_path / "cfgs")
+    cj = tmp_path / "cfgs" / "cfg_eighteen_scenes.yaml"
+    yaml.safe_dump(cfg, open(cj, "w"))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = tmp_path / "res.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "infer_serial.py"), "-c", str(cj), "--seed", "3", "--max-scenes", "16", "--results-json", str(out)]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    sm = json.load(open(out))["summary"]
+    rows_per_scene = cfg["guide"]["batch_size_per_guide"] * len(cfg["guide"]["guides"])
+    assert sm["ranks"] == 8 and sm["scenes"] == 16 and sm["scenes_per_rank"] == [2] * 8 and sm["rows"] == 16 * rows_per_scene
+    for rk in range(1, 8):
+        dk = json.load(open(str(out) + f".rank{rk}"))
+        assert dk["summary"] == sm and len(dk["scenes"]) == 2
+    assert "16 scenes on 8 rank(s)" in r.stdout
 
 
 def test_allreduce_hook_inside_the_device_loop(tiny_net):
