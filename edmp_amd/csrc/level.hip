@@ -67,19 +67,21 @@ __device__ __forceinline__ float lv_group_sum(float x) {
     return x;
 }
 
-template <int MODE, int C, int L, int SB, int CIN>
-__global__ __launch_bounds__(256, (SB <= 2 ? 2 : 1)) void level_kernel(const float* a_src1, const float* a_src2, const float* a_w11, int a_C1, int a_C2, int a_B, LevelP pr) {
-    // (leading scalar arguments = what the input staging needs: preloaded into SGPRs at wave launch, see wide_conv_kernel)
-    LevelP p = pr;
-    p.src1 = a_src1, p.src2 = a_src2, p.w11 = a_w11, p.C1 = a_C1, p.C2 = a_C2, p.B = a_B;
+// The work of one workgroup on one level.  IN_LDS: the level input already sits in this level's (zero-haloed) input tile at the start
+// of `lds` - put there by the previous level of a merged launch (level2_kernel) - instead of being staged from p.src1 / p.src2;
+// OUT_LDS: the resampling conv writes its result into `out_tile` (the NEXT level's input tile, [sample][2 + LOUT + 2][out_rs], which
+// lies inside this level's dead input tile and is cleared here once that tile is dead) instead of p.out.
+template <int MODE, int C, int L, int SB, int CIN, bool IN_LDS = false, bool OUT_LDS = false>
+__device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* out_tile, const int out_rs, const int out_fl) {
     using Cf = LevelCfg<MODE, C, L, SB, CIN>;
+    static_assert(!OUT_LDS || MODE == LV_DOWN, "handing the output over in LDS is built for the down levels");
+    static_assert(!IN_LDS || CIN < 128, "an LDS-resident input is not combined with the chunked staging of the wide up-level inputs");
     constexpr int KX = Cf::KX;
     constexpr int NSLABW = Cf::NSLABW, SBW = Cf::SBW, GS = Cf::GS, MT = Cf::MT, MTMAX = Cf::MTMAX, LOUT = Cf::LOUT;
     constexpr int RSX = Cf::RSX, RSC = Cf::RSC;
     constexpr int LVSLOT = (MODE == LV_DOWN) ? (C == 32 ? 1 : 2) : (MODE == LV_UP ? 3 : 4);  // phase-stamp slot (EDMP_STAMPS builds)
     (void)LVSLOT;
     using f4 = __attribute__((ext_vector_type(4))) float;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     float* TX = lds;
     float* TA = lds + Cf::TX_ALLOC;
     float* TB = TA + Cf::TC_FL;
@@ -126,8 +128,10 @@ __global__ __launch_bounds__(256, (SB <= 2 ? 2 : 1)) void level_kernel(const flo
     // waits for, and memory returns in request order - then RCB 1's first weight fragments; both land while the halos are zeroed
     constexpr int NIT = (SB * L * QCH + 255) / 256;
     float4 vin[NIT];
+    if constexpr (!IN_LDS) {
 #pragma unroll
-    for (int u = 0; u < NIT; ++u) vin[u] = in_load(0, u);
+        for (int u = 0; u < NIT; ++u) vin[u] = in_load(0, u);
+    }
     {
         const float* w = p.w11 + ((size_t)s * (KX / 16)) * (6 * 256) + lane * 4;
 #pragma unroll
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256, (SB <= 2 ? 2 : 1)) void level_kernel(const flo
     //      the padded input channels (level 0: 8 stored channels in a 16-channel K group); then stage the level input
     {
         constexpr int HX = SB * 4 * (RSX / 4), HC = SB * 4 * (RSC / 4);  // float4 items of the halo rows
-        for (int i = tid; i < HX + 2 * HC; i += 256) {
+        for (int i = tid + (IN_LDS ? HX : 0); i < HX + 2 * HC; i += 256) {  // (IN_LDS: the input tile arrived complete, halos and padding included)
             const bool inx = i < HX;
             const int j = inx ? i : (i - HX) % HC;
             const int rs4 = inx ? RSX / 4 : RSC / 4;
@@ -148,13 +152,15 @@ __global__ __launch_bounds__(256, (SB <= 2 ? 2 : 1)) void level_kernel(const flo
             *reinterpret_cast<float4*>(T + row * (inx ? RSX : RSC) + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         constexpr int cq = CIN / 4;  // float4 per input row (C1 + C2 == CIN, checked by the launcher)
-        if constexpr (4 * cq < KX)  // padded channels of the interior rows
+        if constexpr (4 * cq < KX && !IN_LDS)  // padded channels of the interior rows
             for (int i = tid; i < SB * L * (KX / 4 - cq); i += 256) {
                 const int r = i / (KX / 4 - cq), q = cq + i % (KX / 4 - cq);
                 *reinterpret_cast<float4*>(TX + ((r / L) * (L + 4) + r % L + 2) * RSX + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        if constexpr (!IN_LDS) {
 #pragma unroll
-        for (int u = 0; u < NIT; ++u) in_commit(0, u, vin[u]);
+            for (int u = 0; u < NIT; ++u) in_commit(0, u, vin[u]);
+        }
     }
     if (p.stagger_cycles > 0 && ((blockIdx.x >> p.stagger_bit) & 1)) {
         // (the input and the first weight fragments are already on their way / in LDS: the wait costs the late workgroup nothing but time)
@@ -379,6 +385,11 @@ __global__ __launch_bounds__(256, (SB <= 2 ? 2 : 1)) void level_kernel(const flo
         gn_epilogue(EDMP_IC(MT), EDMP_IC(L), p.b11, p.g11, p.be11, [=](int, int, int, int) __attribute__((always_inline)) { return tbv; }, store_tile(TA, L));
     }
     __syncthreads();
+    if constexpr (OUT_LDS) {
+        // the input tile is dead (every wave is past conv1): clear the part the next level's input tile will occupy - its halo rows and
+        // padded channels must read as zeros; several barriers lie between here and the first write into it
+        for (int i = tid; i < out_fl / 4; i += 256) *reinterpret_cast<float4*>(out_tile + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if constexpr (MODE == LV_UP_FINAL) {
         // the input tile is dead (every wave is past conv1): clear the part the up-sampled tile will occupy, so that its halo
         // rows are zero; several barriers lie between here and the first write into it
@@ -436,7 +447,11 @@ __global__ __launch_bounds__(256, (SB <= 2 ? 2 : 1)) void level_kernel(const flo
             for (int r = 0; r < 4; ++r) {
                 const int rho = 16 * m + rq4 + r;
                 const int sm = rho / LOUT, lo = rho - sm * LOUT;
-                if (sm < SBW && b0 + hs + sm < p.B) p.out[((size_t)(b0 + hs + sm) * LOUT + lo) * C + col] = acc[m][r] + brv;
+                if constexpr (OUT_LDS) {
+                    if (sm < SBW) out_tile[((hs + sm) * (LOUT + 4) + lo + 2) * out_rs + col] = acc[m][r] + brv;
+                } else {
+                    if (sm < SBW && b0 + hs + sm < p.B) p.out[((size_t)(b0 + hs + sm) * LOUT + lo) * C + col] = acc[m][r] + brv;
+                }
             }
     } else {
         constexpr int MTE = Cf::MTE, MTR = Cf::MTR, NE = Cf::NE, NO = Cf::NO;
@@ -539,6 +554,33 @@ __global__ __launch_bounds__(256, (SB <= 2 ? 2 : 1)) void level_kernel(const flo
 }
 
 template <int MODE, int C, int L, int SB, int CIN>
+__global__ __launch_bounds__(256, (SB <= 2 ? 2 : 1)) void level_kernel(const float* a_src1, const float* a_src2, const float* a_w11, int a_C1, int a_C2, int a_B, LevelP pr) {
+    // (leading scalar arguments = what the input staging needs: preloaded into SGPRs at wave launch, see wide_conv_kernel)
+    LevelP p = pr;
+    p.src1 = a_src1, p.src2 = a_src2, p.w11 = a_w11, p.C1 = a_C1, p.C2 = a_C2, p.B = a_B;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    level_body<MODE, C, L, SB, CIN>(p, lds, nullptr, 0, 0);
+}
+
+// TWO consecutive down levels in one launch (round 5): level A's k3s2 output goes straight into level B's input tile in LDS - one
+// kernel boundary, one HBM round trip of the activation between them and level B's input staging less per reverse step.  Both levels
+// run the code of level_body on the same SB samples; the workgroup's LDS is the larger of the two levels' needs.
+template <int CA, int LA, int CINA, int CB, int LB, int SB>
+__global__ __launch_bounds__(256, (SB <= 2 ? 2 : 1)) void level2_kernel(const float* a_src1, const float* a_src2, const float* a_w11, int a_C1, int a_C2, int a_B, LevelP pa, LevelP pb) {
+    using CfA = LevelCfg<LV_DOWN, CA, LA, SB, CINA>;
+    using CfB = LevelCfg<LV_DOWN, CB, LB, SB, CA>;
+    static_assert(CfA::LOUT == LB, "level B runs at level A's output length");
+    static_assert(CfB::KX == CA && CfB::TX_FL <= CfA::TX_ALLOC, "level B's input tile fits inside level A's (dead) input tile");
+    LevelP p = pa;
+    p.src1 = a_src1, p.src2 = a_src2, p.w11 = a_w11, p.C1 = a_C1, p.C2 = a_C2, p.B = a_B;
+    pb.B = a_B;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    level_body<LV_DOWN, CA, LA, SB, CINA, false, true>(p, lds, lds, CfB::RSX, CfB::TX_FL);
+    __syncthreads();  // every wave has written its part of level B's input and is done with level A's tiles
+    level_body<LV_DOWN, CB, LB, SB, CA, true, false>(pb, lds, nullptr, 0, 0);
+}
+
+template <int MODE, int C, int L, int SB, int CIN>
 int launch_level_t(const LevelP& p, hipStream_t s) {
     // set once per instance; launches come from several host threads (two contexts: scenes in flight, chains of one batch)
     static std::atomic<int> attr_set{0};
@@ -550,6 +592,22 @@ int launch_level_t(const LevelP& p, hipStream_t s) {
         attr_set.store(1, std::memory_order_release);
     }
     hipLaunchKernelGGL((level_kernel<MODE, C, L, SB, CIN>), dim3((p.B + SB - 1) / SB), dim3(256), bytes, s, p.src1, p.src2, p.w11, p.C1, p.C2, p.B, p);
+    return EDMP_OK;
+}
+
+template <int CA, int LA, int CINA, int CB, int LB, int SB>
+int launch_level2_t(const LevelP& pa, const LevelP& pb, hipStream_t s) {
+    static std::atomic<int> attr_set{0};
+    EDMP_REQUIRE(pa.C1 + pa.C2 == CINA && pa.C1 % 4 == 0 && pa.C2 % 4 == 0 && pb.C1 == CA && pb.C2 == 0, "merged level kernel built for %d -> %d stored input channels, got %d + %d -> %d + %d", CINA,
+                 CA, pa.C1, pa.C2, pb.C1, pb.C2);
+    constexpr size_t ba = LevelCfg<LV_DOWN, CA, LA, SB, CINA>::lds_bytes(), bb = LevelCfg<LV_DOWN, CB, LB, SB, CA>::lds_bytes();
+    constexpr size_t bytes = ba > bb ? ba : bb;
+    static_assert(bytes <= 160 * 1024, "merged level kernel exceeds the 160 KiB LDS of a CU");
+    if (!attr_set.load(std::memory_order_acquire)) {
+        EDMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&level2_kernel<CA, LA, CINA, CB, LB, SB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        attr_set.store(1, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((level2_kernel<CA, LA, CINA, CB, LB, SB>), dim3((pa.B + SB - 1) / SB), dim3(256), bytes, s, pa.src1, pa.src2, pa.w11, pa.C1, pa.C2, pa.B, pa, pb);
     return EDMP_OK;
 }
 

@@ -128,6 +128,7 @@ struct Op {
     int lv_variant;
     int lv_sb;    // samples per workgroup (level_sb, frozen at build time)
     int lv_tb1, lv_tb2;  // offsets of the two blocks' time biases in the time-bias row
+    int lv_merge;        // OP_LVL: 1 = this level and the NEXT op (the following down level) run as one launch (level.hip: level2_kernel)
     int rc_L;     // OP_RCB / OP_WRS: input positions
     int rc_form;  // OP_RCB: 0 direct | 2 / 4 Karatsuba form at L = 2 / 4 (decided when the model was built)
     int rc_ms;    // OP_RCB / OP_WRS: samples per workgroup (wide_ms, frozen at build time)
@@ -392,6 +393,9 @@ EDMP_WIDE_INSTANCES(EDMP_X)
 #undef EDMP_X
 #define EDMP_X(sh, M, C, L, SB, CIN) extern template int launch_level_t<M, C, L, SB, CIN>(const LevelP&, hipStream_t);
 EDMP_LEVEL_INSTANCES(EDMP_X)
+#undef EDMP_X
+#define EDMP_X(sh, CA, LA, CINA, CB, LB, SB) extern template int launch_level2_t<CA, LA, CINA, CB, LB, SB>(const LevelP&, const LevelP&, hipStream_t);
+EDMP_LEVEL2_INSTANCES(EDMP_X)
 #undef EDMP_X
 }  // namespace edmp
 #endif
@@ -663,6 +667,18 @@ static void level_stagger(int variant, int* cycles, int* bit) {
         if (k == variant && !*t) break;
     }
 }
+// EDMP_LEVEL_MERGE=<mask> (read at model-build time): bit 0 = the two down levels of the 32/64-channel resolutions (variants 1 + 2) as
+// ONE launch, level 1's k3s2 output handed to level 2 in LDS (level.hip: level2_kernel; two samples per workgroup)
+static const int kLevelMergeDefault = 0x0;
+static int level_merge_mask() {
+    const char* e = getenv("EDMP_LEVEL_MERGE");
+    return e ? (int)strtol(e, nullptr, 0) : kLevelMergeDefault;
+}
+static int launch_level2(const LevelP& pa, const LevelP& pb, int va, int vb, hipStream_t s) {
+    if (va == 1 && vb == 2) return launch_level2_t<32, 50, 8, 64, 25, 2>(pa, pb, s);
+    set_error("no merged whole-level kernel for variants %d + %d", va, vb);
+    return EDMP_ERR_STATE;
+}
 static int launch_level(const LevelP& p, int variant, int sb, hipStream_t s) {
     switch (variant * 10 + sb) {
         case 14: return launch_level_t<LV_DOWN, 32, 50, 4, 8>(p, s);
@@ -715,6 +731,7 @@ static void op_kernel_name(const Op& op, char* out) {
         snprintf(out, 64, "wide_conv_kernel<%d, %d, %d, %d, %d, %s>", kind, ms, cg < 32 ? 32 : cg, cg, op.rc_L,
                  (op.kind == OP_RCB && op.rc.res_out) ? "true" : "false");
     }
+    else if (op.kind == OP_LVL && op.lv_merge) snprintf(out, 64, "level2_kernel<32, 50, 8, 64, 25, 2>");
     else if (op.kind == OP_LVL) {
         static const char* lv_fmt[] = {"", "level_kernel<0, 32, 50, %d, 8>", "level_kernel<0, 64, 25, %d, 32>", "level_kernel<1, 64, 13, %d, 256>", "level_kernel<2, 32, 25, %d, 128>"};
         snprintf(out, 64, lv_fmt[op.lv_variant], op.lv_sb);
@@ -904,7 +921,7 @@ struct POp {
     int res_out;  // OP_RCB: buffer receiving the folded residual 1x1 conv (-1: none)
     // OP_LVL: offsets of the level's tensors in the packed image, in LevelP order; lv_skip: buffer of the skip output (-1: none)
     size_t lvo[24];
-    int lv_variant, lv_tb1, lv_tb2, lv_skip;
+    int lv_variant, lv_tb1, lv_tb2, lv_skip, lv_merge;
     // fused conv+gn (OP_RCB): uses src1/src2/C1/C2/Lin/Cout/w/b/dst + gamma/beta/res/tb_off
 };
 
@@ -1197,8 +1214,13 @@ struct LayerPlan {
                 pool.put(x.buf);
                 skips.push_back(sk);
                 x = xo;
-                tapr.push_back({i, x.buf, x.C, x.L});
-                pool.pin(x.buf);
+                // merged with the next down level (level2_kernel): this level's output only ever exists in LDS - no tap
+                const bool merged = lvv == 1 && (level_merge_mask() & 1) && i + 1 < nd - 1 && level_variant(LV_DOWN, dm[i + 2], x.L, x.C, 0) == 2;
+                pops.back().lv_merge = merged ? 1 : 0;
+                if (!merged) {
+                    tapr.push_back({i, x.buf, x.C, x.L});
+                    pool.pin(x.buf);
+                }
                 continue;
             }
             TH a = emit_rcb(x, nullptr);
@@ -1347,6 +1369,7 @@ static void resolve_program(UNet* u, const LayerPlan& pl) {
             c.skip_out = o.lv_skip >= 0 ? u->bufs[o.lv_skip] : nullptr;
             c.out = u->bufs[o.dst];
             op.lv_variant = o.lv_variant;
+            op.lv_merge = o.lv_merge;
             op.lv_sb = level_sb(o.lv_variant);
             level_stagger(o.lv_variant, &c.stagger_cycles, &c.stagger_bit);
             op.lv_tb1 = o.lv_tb1;
@@ -1416,6 +1439,13 @@ static void resolve_program(UNet* u, const LayerPlan& pl) {
         op_kernel_name(op, op.name);
         u->prog.push_back(op);
     }
+    // a merged pair is ONE launch, attributed to its first op: that op carries the pair's FLOPs (the model totals are unaffected)
+    for (size_t i = 0; i + 1 < u->prog.size(); ++i)
+        if (u->prog[i].kind == OP_LVL && u->prog[i].lv_merge) {
+            Op &a = u->prog[i], &b = u->prog[i + 1];
+            a.flops_nominal += b.flops_nominal, a.flops_exec += b.flops_exec, a.flops_direct += b.flops_direct;
+            b.flops_nominal = b.flops_exec = b.flops_direct = 0.0;
+        }
 }
 
 // builds the layer program + device weight image.  packed == nullptr: repack `params` (state-dict order) on the host;
@@ -1560,9 +1590,10 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
         EDMP_HIP_CHECK(hipEventRecord(whole.a, main_stream));
     }
     auto coff = [&](auto* q) { return q ? q + unet_chain_offset(u, q, r0) : q; };
-    int op_index = -1;
+    int op_index = -1, skip_index = -1;
     for (const Op& op : u->prog) {
         ++op_index;
+        if (op_index == skip_index) continue;  // the second level of a merged pair: ran inside the previous launch
         hipStream_t s = main_stream;
         EDMP_REQUIRE(!(run_stream && op.branch), "the side-stream build of the layer program (EDMP_SIDE_STREAM) cannot run as row chains");
         if (op.branch == 1) {
@@ -1594,6 +1625,16 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
             p.add_tb = op.tb_off >= 0 ? trow + op.tb_off : nullptr;
             EDMP_REQUIRE(!(p.add_tb && p.add_res), "fused conv block: a launch adds the time bias (conv1) or the residual (conv2), not both");
             rc = launch_rcb(p, op.rc_L, op.rc_form, op.rc_ms, s);
+        } else if (op.kind == OP_LVL && op.lv_merge) {
+            const Op& nx = u->prog[op_index + 1];
+            LevelP pa = op.lv, pb = nx.lv;
+            pa.B = pb.B = B;
+            pa.src1 = coff(pa.src1), pa.src2 = coff(pa.src2), pa.skip_out = coff(pa.skip_out), pa.out = nullptr;
+            pb.src1 = pb.src2 = nullptr, pb.skip_out = coff(pb.skip_out), pb.out = coff(pb.out);
+            pa.tb1 = trow + op.lv_tb1, pa.tb2 = trow + op.lv_tb2;
+            pb.tb1 = trow + nx.lv_tb1, pb.tb2 = trow + nx.lv_tb2;
+            rc = launch_level2(pa, pb, op.lv_variant, nx.lv_variant, s);
+            skip_index = op_index + 1;
         } else if (op.kind == OP_LVL) {
             LevelP p = op.lv;
             p.B = B;
@@ -1654,7 +1695,13 @@ int prof_fold(edmp_ctx* ctx) {
         p.conv_ms += ms;
         if (e.op < 0) {  // whole-program bracket: counts every launch of the program
             if (ctx->unet)
-                for (const Op& op : ctx->unet->prog) p.conv_launches += (op.kind != OP_GN) ? 1 : 0;
+            {
+                bool second_of_pair = false;  // (the second level of a merged pair is not a launch of its own)
+                for (const Op& op : ctx->unet->prog) {
+                    p.conv_launches += (op.kind != OP_GN && !second_of_pair) ? 1 : 0;
+                    second_of_pair = op.kind == OP_LVL && op.lv_merge;
+                }
+            }
         } else {
             p.conv_launches += 1;
         }

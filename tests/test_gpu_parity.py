@@ -183,6 +183,40 @@ def test_sixteen_sample_tiles_of_the_direct_form_instances(monkeypatch):
         assert "wide_conv_kernel<2, 16, 64, 64, 2, false>" in n31 and "wide_conv_kernel<1, 16, 64, 64, 4, false>" in n31
 
 
+def test_merged_down_levels_are_bit_identical_to_two_launches(monkeypatch):
+    """Round 5: EDMP_LEVEL_MERGE=1 runs the two down levels of the 32 / 64-channel resolutions as ONE launch (level.hip: level2_kernel),
+    level 1's k3s2 output handed to level 2 in LDS.  Both levels execute level_body's code on two samples per workgroup, so the forward
+    equals the two-launch program built with two samples per workgroup (EDMP_LEVEL_SB=2222) BIT FOR BIT - whole, ragged and tiny
+    batches - and the oracle within the usual gates; level 1's output has no HBM tap any more."""
+    from edmp_amd import _capi
+    from edmp_amd import weights as W
+    from edmp_amd.temporalunet import TemporalUNet
+    from oracle import edmp_oracle as O
+
+    sd = W.init_state_dict(12, 7, 32, FULL_DIMS)
+    x = torch.tensor(np.random.RandomState(4).standard_normal((70, 7, 50)), dtype=torch.float32)
+    t = torch.tensor([9.0])
+    monkeypatch.setenv("EDMP_LEVEL_SB", "2222")
+    monkeypatch.setenv("EDMP_LEVEL_MERGE", "0")
+    two = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, state_dict=sd, max_batch=70)
+    monkeypatch.setenv("EDMP_LEVEL_MERGE", "1")
+    one = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, state_dict=sd, max_batch=70)
+    monkeypatch.delenv("EDMP_LEVEL_MERGE")
+    monkeypatch.delenv("EDMP_LEVEL_SB")
+    for B in (70, 33, 5, 1):
+        a, b = two(x[:B], t).cpu().numpy(), one(x[:B], t).cpu().numpy()
+        assert np.array_equal(a, b), B
+        if B == 70:
+            assert np.array_equal(two.activation(1, B).cpu().numpy(), one.activation(1, B).cpu().numpy())
+            names = {n for n, _, _, _ in one.ctx.prof_ops()}
+            assert "level2_kernel<32, 50, 8, 64, 25, 2>" in names
+            with pytest.raises(_capi.EdmpError):
+                one.activation(0, B)
+    ref = O.UNetOracle(sd)(x, t).numpy()
+    y = one(x, t).cpu().numpy()
+    assert rmse(y, ref) <= 2e-5 and maxabs(y, ref) <= 2e-4
+
+
 def test_obstacle_table(golden):
     from edmp_amd.guide import IntersectionVolumeGuide
 
