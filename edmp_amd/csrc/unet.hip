@@ -582,7 +582,7 @@ static int rcb_form(int cout, int L) {
 // EDMP_MS16=<mask> (read at model-build time, frozen into the layer program and the packed image's layout id) selects the families:
 // bit 0 Conv1dBlock L = 7 / 256 ch, bit 1 k3s2 L = 7 / 256 ch, bit 2 ConvTranspose L = 4 / 256 ch, bit 3 k3s2 L = 4 / 512 ch,
 // bit 4 ConvTranspose L = 2 / 512 ch.
-static const int kMs16Default = 0x00;
+static const int kMs16Default = 0x05;  // same-box bench A/B, three alternated runs each: 986.5 k -> 989.8 k traj-steps/s (profiles/r05_forkjoin.md); bits 1, 3, 4 measured x0.98-1.01 per launch: off
 static int ms16_mask() {
     const char* e = getenv("EDMP_MS16");
     return e ? (int)strtol(e, nullptr, 0) : kMs16Default;
@@ -669,7 +669,7 @@ static void level_stagger(int variant, int* cycles, int* bit) {
 }
 // EDMP_LEVEL_MERGE=<mask> (read at model-build time): bit 0 = the two down levels of the 32/64-channel resolutions (variants 1 + 2) as
 // ONE launch, level 1's k3s2 output handed to level 2 in LDS (level.hip: level2_kernel; two samples per workgroup)
-static const int kLevelMergeDefault = 0x0;
+static const int kLevelMergeDefault = 0x1;  // same-box bench A/B: 986.5 k -> 988.2 k; with EDMP_MS16=0x05: 991.8 k (profiles/r05_level_kernels.md)
 static int level_merge_mask() {
     const char* e = getenv("EDMP_LEVEL_MERGE");
     return e ? (int)strtol(e, nullptr, 0) : kLevelMergeDefault;

@@ -145,8 +145,9 @@ class TemporalUNet:
     __call__ = forward
 
     def activation(self, which: int, B: int):
-        """(B, C, L) f32 copy of an internal activation of the LAST forward (parity/debug)."""
+        """(B, C, L) f32 copy of an internal activation of THIS model's last forward (parity/debug)."""
         ctx = self.ctx
+        self._bind()  # (every resident model keeps its own activation buffers)
         buf = ctx.empty((B * 4096,), torch.float32)
         c, l = C.c_int(), C.c_int()
         _capi.check(ctx.lib.edmp_unet_read_activation_dev(ctx.h, which, B, ptr(buf), C.byref(c), C.byref(l)))

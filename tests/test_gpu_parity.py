@@ -81,11 +81,18 @@ def test_unet_golden(golden, tag, dims):
         assert rmse(eps, ref) <= 2e-5 and maxabs(eps, ref) <= 2e-4, (tt, rmse(eps, ref), maxabs(eps, ref))
         if tt == 37:  # intermediate activations localise a failure
             n_lv = len(dims)
+            from edmp_amd import _capi
+
             for i in range(n_lv):
-                a = net.activation(i, x.shape[0]).cpu().numpy()
+                try:
+                    a = net.activation(i, x.shape[0]).cpu().numpy()
+                except _capi.EdmpError:
+                    # the first two down levels of the full-size net are one launch (level.hip: level2_kernel, round 5): level 0's
+                    # output only ever exists in LDS; the tap of level 1 right behind it covers it
+                    assert i == 0 and tag == "full"
+                    continue
                 assert maxabs(a, g[f"trace_down{i}"]) <= 5e-4, f"down{i}"
             assert maxabs(net.activation(100, x.shape[0]).cpu().numpy(), g["trace_mid"]) <= 5e-4
-            from edmp_amd import _capi
 
             for j in range(n_lv - 1):
                 try:
@@ -110,7 +117,7 @@ def test_unet_vs_oracle_ragged_batches(oracle, tiny_net):
             assert rmse(a, b) <= 2e-5, (B, tt, rmse(a, b))
 
 
-def test_full_unet_fused_kernels_vs_oracle_ragged(oracle):
+def test_full_unet_fused_kernels_vs_oracle_ragged(oracle, monkeypatch):
     """Full-size net (the fused conv+GroupNorm kernels only exist for its channel widths), batch sizes that are
     not multiples of any tile (32-sample / 2,4,5,9-sample workgroups), every level's activation checked."""
     from edmp_amd import weights as W
@@ -118,6 +125,11 @@ def test_full_unet_fused_kernels_vs_oracle_ragged(oracle):
 
     sd = W.init_state_dict(11, 7, 32, FULL_DIMS)
     net = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, state_dict=sd, max_batch=80)
+    # level 0's output has no HBM tap in the default program (the first two down levels are one launch, round 5): a second model
+    # built with one launch per level serves that tap
+    monkeypatch.setenv("EDMP_LEVEL_MERGE", "0")
+    net_split = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, state_dict=sd, max_batch=80)
+    monkeypatch.delenv("EDMP_LEVEL_MERGE")
     tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
     rs = np.random.RandomState(2)
     for B in (1, 37, 67):
@@ -127,7 +139,11 @@ def test_full_unet_fused_kernels_vs_oracle_ragged(oracle):
             ref = oracle.unet_forward(tsd, x, torch.tensor([123.0]), trace=tr).numpy()
         eps = net(x, torch.tensor([123.0])).cpu().numpy()
         assert rmse(eps, ref) <= 2e-5 and maxabs(eps, ref) <= 2e-4, (B, rmse(eps, ref), maxabs(eps, ref))
-        for i in range(6):
+        eps_split = net_split(x, torch.tensor([123.0])).cpu().numpy()
+        assert rmse(eps_split, ref) <= 2e-5 and maxabs(eps_split, ref) <= 2e-4, (B, "one launch per level")
+        assert maxabs(net_split.activation(0, B).cpu().numpy(), tr["down0"].numpy()) <= 5e-4, (B, "down0")
+        net(x, torch.tensor([123.0]))  # (re-bind the default model: taps read the activations of the last forward)
+        for i in range(1, 6):
             assert maxabs(net.activation(i, B).cpu().numpy(), tr[f"down{i}"].numpy()) <= 5e-4, (B, f"down{i}")
         assert maxabs(net.activation(100, B).cpu().numpy(), tr["mid"].numpy()) <= 5e-4
         for j in range(4):  # up4's activation stays on chip: that level runs as one launch with final_conv.0 (level.hip); eps covers it
