@@ -49,7 +49,9 @@
     X(14, LV_UP, 64, 13, 2, 256)       \
     X(15, LV_UP_FINAL, 32, 25, 2, 128)
 
-// X(shard, CA, LA, CINA, CB, LB, SB): two consecutive down levels in one launch (level.hip: level2_kernel)
-#define EDMP_LEVEL2_INSTANCES(X) X(14, 32, 50, 8, 64, 25, 2)
+// X(shard, MA, CA, LA, CINA, MB, CB, LB, CINB, SB): two consecutive levels in one launch (level.hip: level2_kernel)
+#define EDMP_LEVEL2_INSTANCES(X)                      \
+    X(14, LV_DOWN, 32, 50, 8, LV_DOWN, 64, 25, 32, 2) \
+    X(15, LV_UP, 64, 13, 256, LV_UP_FINAL, 32, 25, 128, 2)
 
 #define EDMP_KERNEL_SHARDS 16

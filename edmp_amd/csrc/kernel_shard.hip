@@ -14,7 +14,7 @@ namespace edmp {
 // instantiate the entries whose shard number is EDMP_SHARD
 #define EDMP_X(sh, K, MS, CG, GS, L, R) EDMP_IF_SHARD(sh, template int launch_wide_t<K, MS, CG, GS, L, R>(const RcbP&, hipStream_t);)
 #define EDMP_Y(sh, M, C, L, SB, CIN) EDMP_IF_SHARD(sh, template int launch_level_t<M, C, L, SB, CIN>(const LevelP&, hipStream_t);)
-#define EDMP_Z(sh, CA, LA, CINA, CB, LB, SB) EDMP_IF_SHARD(sh, template int launch_level2_t<CA, LA, CINA, CB, LB, SB>(const LevelP&, const LevelP&, hipStream_t);)
+#define EDMP_Z(sh, MA, CA, LA, CINA, MB, CB, LB, CINB, SB) EDMP_IF_SHARD(sh, template int launch_level2_t<MA, CA, LA, CINA, MB, CB, LB, CINB, SB>(const LevelP&, const LevelP&, hipStream_t);)
 #define EDMP_IF_SHARD(sh, ...) EDMP_IF_SHARD_I(sh, __VA_ARGS__)
 #define EDMP_IF_SHARD_I(sh, ...) EDMP_SHARD_##sh(__VA_ARGS__)
 #define EDMP_SHARD_0(...)

@@ -67,15 +67,17 @@ __device__ __forceinline__ float lv_group_sum(float x) {
     return x;
 }
 
-// The work of one workgroup on one level.  IN_LDS: the level input already sits in this level's (zero-haloed) input tile at the start
-// of `lds` - put there by the previous level of a merged launch (level2_kernel) - instead of being staged from p.src1 / p.src2;
-// OUT_LDS: the resampling conv writes its result into `out_tile` (the NEXT level's input tile, [sample][2 + LOUT + 2][out_rs], which
-// lies inside this level's dead input tile and is cleared here once that tile is dead) instead of p.out.
-template <int MODE, int C, int L, int SB, int CIN, bool IN_LDS = false, bool OUT_LDS = false>
+// The work of one workgroup on one level.  INR > 0: the first INR of the CIN stored input channels already sit in this level's input
+// tile at the start of `lds` (zero halos included) - put there by the previous level of a merged launch (level2_kernel) - and only
+// channels INR.. are staged from p.src1 / p.src2 (INR == CIN: nothing is); OUT_LDS: the resampling conv writes its result into
+// `out_tile` (the NEXT level's input tile, [sample][2 + LOUT + 2][out_rs], which lies inside this level's dead input tile and is
+// cleared here once that tile is dead) instead of p.out.
+template <int MODE, int C, int L, int SB, int CIN, int INR = 0, bool OUT_LDS = false>
 __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* out_tile, const int out_rs, const int out_fl) {
     using Cf = LevelCfg<MODE, C, L, SB, CIN>;
-    static_assert(!OUT_LDS || MODE == LV_DOWN, "handing the output over in LDS is built for the down levels");
-    static_assert(!IN_LDS || CIN < 128, "an LDS-resident input is not combined with the chunked staging of the wide up-level inputs");
+    constexpr bool IN_LDS = INR == CIN;  // no input staging at all
+    static_assert(!OUT_LDS || MODE == LV_DOWN || MODE == LV_UP, "the last level's output leaves through the step tail / p.out");
+    static_assert(INR == 0 || INR == CIN || (CIN >= 128 && INR % (CIN / 4) == 0), "a partly resident input: whole input chunks");
     constexpr int KX = Cf::KX;
     constexpr int NSLABW = Cf::NSLABW, SBW = Cf::SBW, GS = Cf::GS, MT = Cf::MT, MTMAX = Cf::MTMAX, LOUT = Cf::LOUT;
     constexpr int RSX = Cf::RSX, RSC = Cf::RSC;
@@ -127,10 +129,11 @@ __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* o
     // the first input chunk (all of the input when it is staged in one piece) is requested FIRST - it is what the first MFMA
     // waits for, and memory returns in request order - then RCB 1's first weight fragments; both land while the halos are zeroed
     constexpr int NIT = (SB * L * QCH + 255) / 256;
+    constexpr int FIRSTCH = (INR > 0 && !IN_LDS) ? INR / (CIN / NCH) : 0;  // first input chunk that comes from HBM
     float4 vin[NIT];
     if constexpr (!IN_LDS) {
 #pragma unroll
-        for (int u = 0; u < NIT; ++u) vin[u] = in_load(0, u);
+        for (int u = 0; u < NIT; ++u) vin[u] = in_load(FIRSTCH, u);
     }
     {
         const float* w = p.w11 + ((size_t)s * (KX / 16)) * (6 * 256) + lane * 4;
@@ -141,7 +144,7 @@ __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* o
     //      the padded input channels (level 0: 8 stored channels in a 16-channel K group); then stage the level input
     {
         constexpr int HX = SB * 4 * (RSX / 4), HC = SB * 4 * (RSC / 4);  // float4 items of the halo rows
-        for (int i = tid + (IN_LDS ? HX : 0); i < HX + 2 * HC; i += 256) {  // (IN_LDS: the input tile arrived complete, halos and padding included)
+        for (int i = tid + (INR > 0 ? HX : 0); i < HX + 2 * HC; i += 256) {  // (INR > 0: the previous level cleared the whole input tile before writing into it)
             const bool inx = i < HX;
             const int j = inx ? i : (i - HX) % HC;
             const int rs4 = inx ? RSX / 4 : RSC / 4;
@@ -152,14 +155,14 @@ __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* o
             *reinterpret_cast<float4*>(T + row * (inx ? RSX : RSC) + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         constexpr int cq = CIN / 4;  // float4 per input row (C1 + C2 == CIN, checked by the launcher)
-        if constexpr (4 * cq < KX && !IN_LDS)  // padded channels of the interior rows
+        if constexpr (4 * cq < KX && INR == 0)  // padded channels of the interior rows
             for (int i = tid; i < SB * L * (KX / 4 - cq); i += 256) {
                 const int r = i / (KX / 4 - cq), q = cq + i % (KX / 4 - cq);
                 *reinterpret_cast<float4*>(TX + ((r / L) * (L + 4) + r % L + 2) * RSX + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         if constexpr (!IN_LDS) {
 #pragma unroll
-            for (int u = 0; u < NIT; ++u) in_commit(0, u, vin[u]);
+            for (int u = 0; u < NIT; ++u) in_commit(FIRSTCH, u, vin[u]);
         }
     }
     if (p.stagger_cycles > 0 && ((blockIdx.x >> p.stagger_bit) & 1)) {
@@ -365,15 +368,16 @@ __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* o
         constexpr int KGC = (KX / 16) / NCH;  // K groups per input chunk
         static_for<0, NCH>([&](auto cc) __attribute__((always_inline)) {
             constexpr int c = decltype(cc)::value;
+            constexpr int nxt = FIRSTCH + c + 1;  // the chunk fetched under this chunk's MFMAs (FIRSTCH itself was staged up front)
             float4 v[NITC];
-            if constexpr (c + 1 < NCH) {
+            if constexpr (nxt < NCH) {
 #pragma unroll
-                for (int u = 0; u < NITC; ++u) v[u] = in_load(c + 1, u);
+                for (int u = 0; u < NITC; ++u) v[u] = in_load(nxt, u);
             }
             conv_stage_range(EDMP_IC(MT), EDMP_IC(6), EDMP_IC(6), EDMP_IC(0), P_K5RES, TX, RSX, KX / 16, p.w11, ab, bf, c * KGC, (c + 1) * KGC);
-            if constexpr (c + 1 < NCH) {
+            if constexpr (nxt < NCH) {
 #pragma unroll
-                for (int u = 0; u < NITC; ++u) in_commit(c + 1, u, v[u]);
+                for (int u = 0; u < NITC; ++u) in_commit(nxt, u, v[u]);
                 __syncthreads();
             }
         });
@@ -475,6 +479,7 @@ __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* o
                 if (sm < SBW) {
                     const float y = acc[m][r] + brv;
                     if constexpr (MODE == LV_UP_FINAL) TF[((hs + sm) * (LOUT + 4) + lo + 2) * RSC + col] = y;
+                    else if constexpr (OUT_LDS) out_tile[((hs + sm) * (LOUT + 4) + lo + 2) * out_rs + col] = y;
                     else if (b0 + hs + sm < p.B) p.out[((size_t)(b0 + hs + sm) * LOUT + lo) * C + col] = y;
                 }
             }
@@ -562,22 +567,24 @@ __global__ __launch_bounds__(256, (SB <= 2 ? 2 : 1)) void level_kernel(const flo
     level_body<MODE, C, L, SB, CIN>(p, lds, nullptr, 0, 0);
 }
 
-// TWO consecutive down levels in one launch (round 5): level A's k3s2 output goes straight into level B's input tile in LDS - one
-// kernel boundary, one HBM round trip of the activation between them and level B's input staging less per reverse step.  Both levels
-// run the code of level_body on the same SB samples; the workgroup's LDS is the larger of the two levels' needs.
-template <int CA, int LA, int CINA, int CB, int LB, int SB>
+// TWO consecutive levels in one launch (round 5): level A's resampled output goes straight into level B's input tile in LDS - one
+// kernel boundary, one HBM round trip of the activation between them and (that part of) level B's input staging less per reverse
+// step.  Both levels run the code of level_body on the same SB samples; the workgroup's LDS is the larger of the two levels' needs.
+// Instances: the two down levels of the 32 / 64-channel resolutions; the two last up levels (level B's input = level A's output
+// followed by the skip tensor, which still comes from HBM).
+template <int MA, int CA, int LA, int CINA, int MB, int CB, int LB, int CINB, int SB>
 __global__ __launch_bounds__(256, (SB <= 2 ? 2 : 1)) void level2_kernel(const float* a_src1, const float* a_src2, const float* a_w11, int a_C1, int a_C2, int a_B, LevelP pa, LevelP pb) {
-    using CfA = LevelCfg<LV_DOWN, CA, LA, SB, CINA>;
-    using CfB = LevelCfg<LV_DOWN, CB, LB, SB, CA>;
+    using CfA = LevelCfg<MA, CA, LA, SB, CINA>;
+    using CfB = LevelCfg<MB, CB, LB, SB, CINB>;
     static_assert(CfA::LOUT == LB, "level B runs at level A's output length");
-    static_assert(CfB::KX == CA && CfB::TX_FL <= CfA::TX_ALLOC, "level B's input tile fits inside level A's (dead) input tile");
+    static_assert(CfB::KX == CINB && CINB >= CA && CfB::TX_FL <= CfA::TX_ALLOC, "level B's input tile fits inside level A's (dead) input tile");
     LevelP p = pa;
     p.src1 = a_src1, p.src2 = a_src2, p.w11 = a_w11, p.C1 = a_C1, p.C2 = a_C2, p.B = a_B;
     pb.B = a_B;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    level_body<LV_DOWN, CA, LA, SB, CINA, false, true>(p, lds, lds, CfB::RSX, CfB::TX_FL);
+    level_body<MA, CA, LA, SB, CINA, 0, true>(p, lds, lds, CfB::RSX, CfB::TX_FL);
     __syncthreads();  // every wave has written its part of level B's input and is done with level A's tiles
-    level_body<LV_DOWN, CB, LB, SB, CA, true, false>(pb, lds, nullptr, 0, 0);
+    level_body<MB, CB, LB, SB, CINB, CA, false>(pb, lds, nullptr, 0, 0);
 }
 
 template <int MODE, int C, int L, int SB, int CIN>
@@ -595,19 +602,19 @@ int launch_level_t(const LevelP& p, hipStream_t s) {
     return EDMP_OK;
 }
 
-template <int CA, int LA, int CINA, int CB, int LB, int SB>
+template <int MA, int CA, int LA, int CINA, int MB, int CB, int LB, int CINB, int SB>
 int launch_level2_t(const LevelP& pa, const LevelP& pb, hipStream_t s) {
     static std::atomic<int> attr_set{0};
-    EDMP_REQUIRE(pa.C1 + pa.C2 == CINA && pa.C1 % 4 == 0 && pa.C2 % 4 == 0 && pb.C1 == CA && pb.C2 == 0, "merged level kernel built for %d -> %d stored input channels, got %d + %d -> %d + %d", CINA,
-                 CA, pa.C1, pa.C2, pb.C1, pb.C2);
-    constexpr size_t ba = LevelCfg<LV_DOWN, CA, LA, SB, CINA>::lds_bytes(), bb = LevelCfg<LV_DOWN, CB, LB, SB, CA>::lds_bytes();
+    EDMP_REQUIRE(pa.C1 + pa.C2 == CINA && pa.C1 % 4 == 0 && pa.C2 % 4 == 0 && pb.C1 == CA && pb.C1 + pb.C2 == CINB, "merged level kernel built for %d -> %d + %d stored input channels, got %d + %d -> %d + %d",
+                 CINA, CA, CINB - CA, pa.C1, pa.C2, pb.C1, pb.C2);
+    constexpr size_t ba = LevelCfg<MA, CA, LA, SB, CINA>::lds_bytes(), bb = LevelCfg<MB, CB, LB, SB, CINB>::lds_bytes();
     constexpr size_t bytes = ba > bb ? ba : bb;
     static_assert(bytes <= 160 * 1024, "merged level kernel exceeds the 160 KiB LDS of a CU");
     if (!attr_set.load(std::memory_order_acquire)) {
-        EDMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&level2_kernel<CA, LA, CINA, CB, LB, SB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        EDMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&level2_kernel<MA, CA, LA, CINA, MB, CB, LB, CINB, SB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         attr_set.store(1, std::memory_order_release);
     }
-    hipLaunchKernelGGL((level2_kernel<CA, LA, CINA, CB, LB, SB>), dim3((pa.B + SB - 1) / SB), dim3(256), bytes, s, pa.src1, pa.src2, pa.w11, pa.C1, pa.C2, pa.B, pa, pb);
+    hipLaunchKernelGGL((level2_kernel<MA, CA, LA, CINA, MB, CB, LB, CINB, SB>), dim3((pa.B + SB - 1) / SB), dim3(256), bytes, s, pa.src1, pa.src2, pa.w11, pa.C1, pa.C2, pa.B, pa, pb);
     return EDMP_OK;
 }
 

@@ -394,7 +394,7 @@ EDMP_WIDE_INSTANCES(EDMP_X)
 #define EDMP_X(sh, M, C, L, SB, CIN) extern template int launch_level_t<M, C, L, SB, CIN>(const LevelP&, hipStream_t);
 EDMP_LEVEL_INSTANCES(EDMP_X)
 #undef EDMP_X
-#define EDMP_X(sh, CA, LA, CINA, CB, LB, SB) extern template int launch_level2_t<CA, LA, CINA, CB, LB, SB>(const LevelP&, const LevelP&, hipStream_t);
+#define EDMP_X(sh, MA, CA, LA, CINA, MB, CB, LB, CINB, SB) extern template int launch_level2_t<MA, CA, LA, CINA, MB, CB, LB, CINB, SB>(const LevelP&, const LevelP&, hipStream_t);
 EDMP_LEVEL2_INSTANCES(EDMP_X)
 #undef EDMP_X
 }  // namespace edmp
@@ -668,14 +668,17 @@ static void level_stagger(int variant, int* cycles, int* bit) {
     }
 }
 // EDMP_LEVEL_MERGE=<mask> (read at model-build time): bit 0 = the two down levels of the 32/64-channel resolutions (variants 1 + 2) as
-// ONE launch, level 1's k3s2 output handed to level 2 in LDS (level.hip: level2_kernel; two samples per workgroup)
-static const int kLevelMergeDefault = 0x1;  // same-box bench A/B: 986.5 k -> 988.2 k; with EDMP_MS16=0x05: 991.8 k (profiles/r05_level_kernels.md)
+// ONE launch, level 1's k3s2 output handed to level 2 in LDS (level.hip: level2_kernel; two samples per workgroup); bit 1 = the two
+// last up levels (variants 3 + 4) likewise, the ConvTranspose output of the 64-channel level going into the first half of the last
+// level's input tile (the skip half still comes from HBM)
+static const int kLevelMergeDefault = 0x3;  // same-box bench A/B, three alternated runs each: bit 0 986.5 k -> 988.2 k; bits 0 + 1 993.8 k -> 997.7 k, bit 1 alone 992.5 k (profiles/r05_level_kernels.md)
 static int level_merge_mask() {
     const char* e = getenv("EDMP_LEVEL_MERGE");
     return e ? (int)strtol(e, nullptr, 0) : kLevelMergeDefault;
 }
 static int launch_level2(const LevelP& pa, const LevelP& pb, int va, int vb, hipStream_t s) {
-    if (va == 1 && vb == 2) return launch_level2_t<32, 50, 8, 64, 25, 2>(pa, pb, s);
+    if (va == 1 && vb == 2) return launch_level2_t<LV_DOWN, 32, 50, 8, LV_DOWN, 64, 25, 32, 2>(pa, pb, s);
+    if (va == 3 && vb == 4) return launch_level2_t<LV_UP, 64, 13, 256, LV_UP_FINAL, 32, 25, 128, 2>(pa, pb, s);
     set_error("no merged whole-level kernel for variants %d + %d", va, vb);
     return EDMP_ERR_STATE;
 }
@@ -731,7 +734,7 @@ static void op_kernel_name(const Op& op, char* out) {
         snprintf(out, 64, "wide_conv_kernel<%d, %d, %d, %d, %d, %s>", kind, ms, cg < 32 ? 32 : cg, cg, op.rc_L,
                  (op.kind == OP_RCB && op.rc.res_out) ? "true" : "false");
     }
-    else if (op.kind == OP_LVL && op.lv_merge) snprintf(out, 64, "level2_kernel<32, 50, 8, 64, 25, 2>");
+    else if (op.kind == OP_LVL && op.lv_merge) snprintf(out, 64, op.lv_variant == 1 ? "level2_kernel<0, 32, 50, 8, 0, 64, 25, 32, 2>" : "level2_kernel<1, 64, 13, 256, 2, 32, 25, 128, 2>");
     else if (op.kind == OP_LVL) {
         static const char* lv_fmt[] = {"", "level_kernel<0, 32, 50, %d, 8>", "level_kernel<0, 64, 25, %d, 32>", "level_kernel<1, 64, 13, %d, 256>", "level_kernel<2, 32, 25, %d, 128>"};
         snprintf(out, 64, lv_fmt[op.lv_variant], op.lv_sb);
@@ -1270,8 +1273,14 @@ struct LayerPlan {
                     if (mode == LV_UP_FINAL) {
                         final_fused = true;  // the level kernel already applied final_conv.0
                     } else {
-                        tapr.push_back({200 + j, x.buf, x.C, x.L});
-                        pool.pin(x.buf);
+                        // merged with the last up level (level2_kernel): this level's output only ever exists in LDS - no tap
+                        const bool merged = lvv == 3 && (level_merge_mask() & 2) && i == 3 && !skips.empty() && dm[1] == dm[i - 2] && 2 * x.L == N &&
+                                            level_variant(LV_UP_FINAL, dm[i - 2], x.L, x.C, skips.back().C) == 4;
+                        pops.back().lv_merge = merged ? 1 : 0;
+                        if (!merged) {
+                            tapr.push_back({200 + j, x.buf, x.C, x.L});
+                            pool.pin(x.buf);
+                        }
                     }
                     continue;
                 }
@@ -1590,6 +1599,16 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
         EDMP_HIP_CHECK(hipEventRecord(whole.a, main_stream));
     }
     auto coff = [&](auto* q) { return q ? q + unet_chain_offset(u, q, r0) : q; };
+    // the tail of the reverse step runs inside the last level's launch when that level is the program's last op (LV_UP_FINAL, 32 channels)
+    auto fuse_step_tail = [&](LevelP& p, const Op& o, int index, bool out_is_head_input) {
+        if (tail && tail_done && o.lv_variant == 4 && index + 1 == (int)u->prog.size() && u->head_cin == 32 && tail->N == u->desc.horizon && tail->C <= 8 && out_is_head_input && u->fuse_tail) {
+            p.tail = *tail;
+            p.tail.on = 1;
+            p.tail.w = u->head_w;
+            p.tail.bias = u->head_b;
+            *tail_done = true;
+        }
+    };
     int op_index = -1, skip_index = -1;
     for (const Op& op : u->prog) {
         ++op_index;
@@ -1629,10 +1648,12 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
             const Op& nx = u->prog[op_index + 1];
             LevelP pa = op.lv, pb = nx.lv;
             pa.B = pb.B = B;
+            const bool out_is_head_input = pb.out == u->h_last;
             pa.src1 = coff(pa.src1), pa.src2 = coff(pa.src2), pa.skip_out = coff(pa.skip_out), pa.out = nullptr;
-            pb.src1 = pb.src2 = nullptr, pb.skip_out = coff(pb.skip_out), pb.out = coff(pb.out);
+            pb.src1 = nullptr, pb.src2 = coff(pb.src2), pb.skip_out = coff(pb.skip_out), pb.out = coff(pb.out);  // (level B's first input half arrives in LDS)
             pa.tb1 = trow + op.lv_tb1, pa.tb2 = trow + op.lv_tb2;
             pb.tb1 = trow + nx.lv_tb1, pb.tb2 = trow + nx.lv_tb2;
+            fuse_step_tail(pb, nx, op_index + 1, out_is_head_input);
             rc = launch_level2(pa, pb, op.lv_variant, nx.lv_variant, s);
             skip_index = op_index + 1;
         } else if (op.kind == OP_LVL) {
@@ -1642,13 +1663,7 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
             p.src1 = coff(p.src1), p.src2 = coff(p.src2), p.skip_out = coff(p.skip_out), p.out = coff(p.out);
             p.tb1 = trow + op.lv_tb1;
             p.tb2 = trow + op.lv_tb2;
-            if (tail && tail_done && op.lv_variant == 4 && op_index + 1 == (int)u->prog.size() && u->head_cin == 32 && tail->N == u->desc.horizon && tail->C <= 8 && out_is_head_input && u->fuse_tail) {
-                p.tail = *tail;
-                p.tail.on = 1;
-                p.tail.w = u->head_w;
-                p.tail.bias = u->head_b;
-                *tail_done = true;
-            }
+            fuse_step_tail(p, op, op_index, out_is_head_input);
             rc = launch_level(p, op.lv_variant, op.lv_sb, s);
         } else if (op.kind == OP_WRS) {
             RcbP p = op.rc;
