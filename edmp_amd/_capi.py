@@ -100,6 +100,14 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  edmp_amd has no CPU fallback."
         )
+    # PyTorch-ROCm carries its own libamdhip64: map it FIRST, so that the process has ONE HIP runtime (our library then binds to the copy
+    # already loaded).  In the other order - this library pulling /opt/rocm's runtime, torch its own afterwards (what
+    # `python __graft_entry__.py smoke` did: build() loads the library before anything imported torch) - the process holds two runtimes
+    # and the second one reports "no ROCm-capable device".  A host without torch (tests/c_abi) links the system runtime alone.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover
+        pass
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover

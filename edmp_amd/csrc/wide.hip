@@ -113,7 +113,7 @@ struct WideCfg {
     static constexpr int S = CG / SW;                // output slabs per workgroup
     static constexpr int KSPLIT = NW / S;            // waves sharing a slab, each with its own K slice
     // channels per staged chunk = one barrier (64-channel chunks were measured neutral for the Karatsuba form: -2 % K loop, +1 k cycles of prologue)
-    static constexpr int KC = (KG * KSPLIT > 32) ? KG * KSPLIT : 32;
+    static constexpr int KC = (BIL && MS == 16) ? 64 : (KG * KSPLIT > 32) ? KG * KSPLIT : 32;  // (16-sample bilinear tiles: 64 channels make the staging map one item per thread)
     static constexpr int QW = KC / KG / KSPLIT;      // K groups per wave per chunk
     static constexpr int LDK = KC + 4;
     static constexpr int KT0 = (KIND == WK_K5 && LIN == 2) ? 1 : 0;  // first tap that can be valid
@@ -418,13 +418,15 @@ __device__ __forceinline__ void wide_conv_body(const RcbP& p, const int grp, con
                             if constexpr (Cf::slot(a, v) >= 0) {
                                 const float4& bq = bc[q][Cf::slot(a, v) >= 0 ? Cf::slot(a, v) : 0];
                                 const float bx = (J == 0) ? bq.x : (J == 1) ? bq.y : (J == 2) ? bq.z : bq.w;
-                                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bx, acc[a], 0, 0, 0);
+                                if constexpr (MS == 32) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bx, acc[a], 0, 0, 0);
+                                else acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bx, acc[a], 0, 0, 0);
                             }
                         });
                         if constexpr (RES && Cf::rawpos(v) >= 0) {
                             const float4& bq = bc[q][NTAP];
                             const float bx = (J == 0) ? bq.x : (J == 1) ? bq.y : (J == 2) ? bq.z : bq.w;
-                            racc[Cf::rawpos(v) >= 0 ? Cf::rawpos(v) : 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bx, racc[Cf::rawpos(v) >= 0 ? Cf::rawpos(v) : 0], 0, 0, 0);
+                            if constexpr (MS == 32) racc[Cf::rawpos(v) >= 0 ? Cf::rawpos(v) : 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bx, racc[Cf::rawpos(v) >= 0 ? Cf::rawpos(v) : 0], 0, 0, 0);
+                            else racc[Cf::rawpos(v) >= 0 ? Cf::rawpos(v) : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bx, racc[Cf::rawpos(v) >= 0 ? Cf::rawpos(v) : 0], 0, 0, 0);
                         }
                         if constexpr (J == 0 && !(FIRST && q + 1 == QW)) {  // the next K group's fragment of this position
                             const float* nx = (q + 1 < QW) ? st + frag + KG * (q + 1) : stn + frag;
