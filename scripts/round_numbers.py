@@ -50,12 +50,12 @@ if c:
 print("\n| kernel | launches | avg us | share | TFLOP/s issued | frac |\n|---|---:|---:|---:|---:|---:|")
 for r in rf["per_kernel"]:
     print(f"| `{r['kernel']}` | {r['launches']} | {r['avg_us']:.2f} | {r['share']:.3f} | {r['executed_tflops']:.1f} | {r['frac']:.3f} |")
-lv = [r for r in rf["per_kernel"] if r["kernel"].startswith("level_kernel")]
+lv = [r for r in rf["per_kernel"] if r["kernel"].startswith(("level_kernel", "level2_kernel"))]
 print(f"\nLevel kernels per reverse step: {sum(r['avg_us'] for r in lv):.1f} us in {len(lv)} launches.")
 
 print(f"\n## rocprofv3 kernel trace of the same command (`{R}_kernel_stats.csv`)\n")
 rows = list(csv.DictReader(open(os.path.join(P, f"{R}_kernel_stats.csv"))))
-conv = [r for r in rows if "wide_conv_kernel" in r["Name"] or "level_kernel" in r["Name"] or "l2_chain_kernel" in r["Name"]]
+conv = [r for r in rows if "wide_conv_kernel" in r["Name"] or "level_kernel" in r["Name"] or "level2_kernel" in r["Name"]]
 tot_ns = sum(int(r["TotalDurationNs"]) for r in conv)
 calls = sum(int(r["Calls"]) for r in conv)
 dom = [r for r in rows if "wide_conv_kernel<3, 32, 64, 64, 2, false>" in r["Name"].replace("(edmp::WideKind)", "")]
@@ -72,6 +72,6 @@ h = json.load(open(os.path.join(P, f"{R}_pmc_hbm_traffic.json")))["conv_family"]
 print(f"* HBM traffic: {h['hbm_MB_per_forward']:.0f} MB per forward over {h['launches_per_forward']} launches = {h['hbm_MB_per_launch']:.1f} MB per launch, {h['hbm_bytes_per_traj_step'] / 1e6:.3f} MB per trajectory-step "
       f"(algorithmic 0.121 MB: x{h['hbm_bytes_per_traj_step'] / 121147:.1f})")
 for line in open(os.path.join(P, f"{R}_pmc_mfma_util.md")):
-    if line.startswith("| `level_kernel") or line.startswith("| **all") or "<3, 32, 64, 64, 2, false>" in line:
+    if line.startswith(("| `level_kernel", "| `level2_kernel")) or line.startswith("| **all") or "<3, 32, 64, 64, 2, false>" in line:
         c = [x.strip() for x in line.strip().strip("|").split("|")]
         print(f"* MFMA busy of kernel wall time @2.4 GHz: {c[0]} -> {c[-1]} %")

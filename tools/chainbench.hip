@@ -2,6 +2,7 @@
 // 512 -> 512 at L = 2 (Karatsuba form) ping-ponging between two activation buffers, B = 1024.  Checks bit-equality of the final
 // activations, times both (chains of 20 repetitions, best of 6) and prints the per-layer shader-clock stamps of workgroup 0 of the chain
 // kernel: wait in the cluster gate | body | arrive.
+// (round 5: chain.hip left the library; `git apply tools/experiments/r04_l2_chain.patch` restores it for this tool)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-kernarg-preload-count=12 tools/chainbench.hip -o tools/chainbench && tools/chainbench [n = 13]
 #define EDMP_CHAIN_STAMPS 1
 #define EDMP_CHAIN_DEFINE 1
