@@ -59,6 +59,7 @@ class Context:
             self.h = None
             self.bound_model = self.bound_guide = None
             self._pinned = None
+            self._scene_noise_buffers = None  # (infer_serial's whole-scene pinned noise buffers of scenes in flight)
             for key in [k for k, v in _contexts.items() if v is self] + [k for k, v in _lane_contexts.items() if v is self]:
                 _contexts.pop(key, None)
                 _lane_contexts.pop(key, None)

@@ -192,6 +192,45 @@ def test_row_classes():
     assert rc.tolist() == [0, 0, 0, 1, 1, 1, 0, 0, 0, 2, 2, 2] and cc.shape == (3, T) and ce.shape == (3, T)
 
 
+def test_row_classes_vectorised_form_equals_the_row_by_row_definition():
+    """round 5: runs of equal rows are keyed once (the guide object is rebuilt per scene); any row order, NaN and signed-zero rows and
+    a single row must give what the row-by-row dictionary gives: classes numbered by first appearance, representatives = first rows"""
+    from edmp_amd.guide import row_classes
+
+    def by_rows(clr, exp):
+        keys, reps, rc = {}, [], []
+        for b in range(clr.shape[0]):
+            k = (clr[b].tobytes(), exp[b].tobytes())
+            if k not in keys:
+                keys[k] = len(reps)
+                reps.append(b)
+            rc.append(keys[k])
+        return np.array(rc, dtype=np.int32), clr[reps], exp[reps]
+
+    c = cfgs_for([1, 2, 3, 4, 5, 10], 171)
+    clr, exp = np.asarray(c["clearance"], dtype=np.float64).copy(), np.asarray(c["expansion"], dtype=np.float64).copy()
+    clr[7, 3], clr[8, 3] = np.nan, np.nan  # two equal NaN rows: one class (byte-wise keys)
+    exp[500, 0], exp[501, 0] = 0.0, -0.0    # signed zeros differ byte-wise
+    perm = np.random.RandomState(3).permutation(clr.shape[0])
+    for a, b in ((clr, exp), (clr[perm], exp[perm]), (clr[:1], exp[:1]), (clr[5:9], exp[5:9])):
+        got, want = row_classes(a, b), by_rows(a, b)
+        assert np.array_equal(got[0], want[0]) and got[0].dtype == np.int32
+        assert np.array_equal(got[1], want[1], equal_nan=True) and np.array_equal(got[2], want[2], equal_nan=True)
+
+
+def test_total_rows_extension_of_the_run_config():
+    """`guide.total_rows` (not in the reference's schema, which only allows B = G * batch_size_per_guide): BASELINE's 'batch = 1024 with
+    six guides' as contiguous row blocks; absent -> the reference's arrays"""
+    from edmp_amd import guide_cfg as GC
+
+    run = {"guide": {"guides": [1, 2, 3, 4, 5, 10], "batch_size_per_guide": 170}, "model": {"T": T}}
+    assert GC.guide_cfgs_from_run_cfg(run)["total_batch_size"] == 1020
+    run["guide"]["total_rows"] = 1024
+    c = GC.guide_cfgs_from_run_cfg(run)
+    ref = GC.build_guide_cfgs([GC.catalog_guide_dict(n) for n in run["guide"]["guides"]], 170, T, rows_per_guide=GC.split_rows(1024, 6))
+    assert c["total_batch_size"] == 1024 and all(np.array_equal(c[k], ref[k]) for k in ("clearance", "expansion", "guidance_method", "grad_norm", "guidance_schedule"))
+
+
 def test_scene_contract():
     from edmp_amd import scenes
 
