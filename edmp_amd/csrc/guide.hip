@@ -149,6 +149,17 @@ struct Vec3 {
     float x, y, z;
 };
 
+__device__ __forceinline__ float hw_max(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float hw_min(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ float comp(const Vec3& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
 
 // corner v of link box (half extents he) under transform [R|o]: world position
@@ -193,6 +204,8 @@ __global__ __launch_bounds__(256, (SPLIT == 4 ? 4 : 1)) void guide_kernel(GuideA
         }
     }
     __syncthreads();
+    // (scalar loads of the wave-uniform obstacle values straight from the table instead of LDS reads were tried in round 5: as many VALU
+    // instructions - an SGPR operand per instruction, the rest moved into VGPRs - and the loads' latency in the loop: not kept)
     const float* obs = s_obs[SPLIT == 4 ? 0 : wv];
     // SPLIT = 4: this wave's links and the last joint frame it needs
     const int my_jmax = (SPLIT == 4) ? (wv == 0 ? 2 : wv == 1 ? 4 : 6) : 6;
@@ -335,8 +348,10 @@ __global__ __launch_bounds__(256, (SPLIT == 4 ? 4 : 1)) void guide_kernel(GuideA
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float om = ab[k], oM = ab[3 + k];
-                    const float lo = fmaxf(bmin[k], om);
-                    const float hi = fminf(bmax[k], oM);
+                    // (the hardware instruction itself: fmaxf / fminf make the compiler canonicalise every LDS-loaded operand first -
+                    // one extra v_max_f32 x, x per obstacle value, 10 % of this loop; the table holds finite numbers)
+                    const float lo = hw_max(bmin[k], om);
+                    const float hi = hw_min(bmax[k], oM);
                     len[k] = hi - lo;
                     cl[k] = len[k] > 0.f ? len[k] : 0.f;
                     wlo[k] = bmin[k] > om ? 1.f : (bmin[k] == om ? 0.5f : 0.f);
