@@ -40,6 +40,13 @@ struct LevelCfg {
     static constexpr int GS = C / 8;               // channels per GroupNorm group
     static constexpr int ROWS = SBW * L;
     static constexpr int MT = (ROWS + 15) / 16;
+    // a last row tile with <= 4 real rows runs on v_mfma_f32_4x4x1_16B_f32 (16 blocks of 4x4, K = 1: the blocks = 4 column groups x the four
+    // k of a fragment component; 10.5 cycles instead of 32, tools/mfma4x4_probe.hip): 50 rows cost 3 x 32 + 10.5 cycles per K step, not 128
+#ifdef EDMP_NO_SMALL_TILE
+    static constexpr bool small_tile(int rows, int mt) { return false && rows + mt > 0; }
+#else
+    static constexpr bool small_tile(int rows, int mt) { return rows - 16 * (mt - 1) <= 4; }
+#endif
     static constexpr int LOUT = (MODE == LV_DOWN) ? (L - 1) / 2 + 1 : ((2 * L == 8 || 2 * L == 14 || 2 * L == 26) ? 2 * L - 1 : 2 * L);
     static constexpr int NE = (LOUT + 1) / 2, NO = LOUT / 2;  // even / odd output positions of the transposed conv
     static constexpr int MTE = (SBW * NE + 15) / 16, MTO = (SBW * NO + 15) / 16;
@@ -188,9 +195,10 @@ __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* o
 #pragma unroll
         for (int t = 0; t < NSLOT; ++t) b[t] = *reinterpret_cast<const float4*>(w + t * 256);
     };
-    auto conv_stage_range = [&](auto mtn_c, auto npair_c, auto nslot_c, auto mtsplit_c, auto pairs, const float* tile, int RS, int nkg, const float* wstream,
+    auto conv_stage_range = [&](auto mtn_c, auto npair_c, auto nslot_c, auto mtsplit_c, auto small_c, auto pairs, const float* tile, int RS, int nkg, const float* wstream,
                                 const int(&ab)[MTMAX], float4(&bfirst)[6], int kg0, int kg1) __attribute__((always_inline)) {
         constexpr int MTN = decltype(mtn_c)::value, NPAIR = decltype(npair_c)::value, NSLOT = decltype(nslot_c)::value, MTSPLIT = decltype(mtsplit_c)::value;
+        constexpr bool SMALL = decltype(small_c)::value != 0;  // the last tile holds <= 4 rows: 4x4x1 blocks, partial sums per k quarter (small_tile_finish)
         const float* w = wstream + ((size_t)s * nkg) * (NSLOT * 256) + lane * 4;
         float4 bcur[NSLOT], bnxt[NSLOT];
 #pragma unroll
@@ -225,7 +233,10 @@ __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* o
 #define EDMP_LV_ROUND(J)                                                                                     \
     static_for<m_lo, m_hi>([&](auto mc) __attribute__((always_inline)) {                                   \
         constexpr int m = decltype(mc)::value;                                                               \
-        if constexpr (tgt == 0) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].J, bcur[slot].J, acc[m], 0, 0, 0); \
+        if constexpr (SMALL && m == MTN - 1) {                                                               \
+            if constexpr (tgt == 0) acc[m] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[m].J, bcur[slot].J, acc[m], 0, 0, 0); \
+            else racc[m < MT ? m : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[m].J, bcur[slot].J, racc[m < MT ? m : 0], 0, 0, 0); \
+        } else if constexpr (tgt == 0) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].J, bcur[slot].J, acc[m], 0, 0, 0); \
         else racc[m < MT ? m : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].J, bcur[slot].J, racc[m < MT ? m : 0], 0, 0, 0); \
     });
                 EDMP_LV_ROUND(x)
@@ -248,17 +259,27 @@ __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* o
 #pragma unroll
         for (int t = 0; t < NSLOT; ++t) bfirst[t] = bcur[t];  // a following range of the same stage continues with these
     };
-    auto conv_stage = [&](auto mtn_c, auto npair_c, auto nslot_c, auto mtsplit_c, auto pairs, const float* tile, int RS, int nkg, const float* wstream,
+    // after the last K group of a stage whose last tile ran on 4x4x1 blocks: lane group q (16 lanes) holds the partial sums over the k = q
+    // (mod 4) of rows 0..3 of that tile; their sum (fixed order (q0 + q1) + (q2 + q3)) lands in every group - group 0's registers then mean
+    // what the 16x16x4 layout says (rows 0..3), the other groups' rows >= 4 are padding the epilogues never look at
+    auto small_tile_finish = [&](f4& t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = swap32_add(swap16_add(t[r]));
+    };
+    auto conv_stage = [&](auto mtn_c, auto npair_c, auto nslot_c, auto mtsplit_c, auto small_c, auto pairs, const float* tile, int RS, int nkg, const float* wstream,
                           const int(&ab)[MTMAX], float4(&bfirst)[6]) __attribute__((always_inline)) {
-        conv_stage_range(mtn_c, npair_c, nslot_c, mtsplit_c, pairs, tile, RS, nkg, wstream, ab, bfirst, 0, nkg);
+        conv_stage_range(mtn_c, npair_c, nslot_c, mtsplit_c, small_c, pairs, tile, RS, nkg, wstream, ab, bfirst, 0, nkg);
+        if constexpr (decltype(small_c)::value != 0) small_tile_finish(acc[decltype(mtn_c)::value - 1]);
     };
 
     // A-row offsets of a stride-1 k5 stage over a tile with LL positions per sample and row stride RS
-    auto rows_k5 = [&](auto mtn_c, int LL, int RS, int (&ab)[MTMAX]) __attribute__((always_inline)) {
+    auto rows_k5 = [&](auto mtn_c, auto small_c, int LL, int RS, int (&ab)[MTMAX]) __attribute__((always_inline)) {
         constexpr int MTN = decltype(mtn_c)::value;
+        constexpr bool SMALL = decltype(small_c)::value != 0;
 #pragma unroll
         for (int m = 0; m < MTN; ++m) {
-            const int rho = min(16 * m + (lane & 15), SBW * LL - 1);
+            // (a 4x4x1-block tile: lane l feeds row l % 4 of the tile - the four column groups of a k quarter read the same rows)
+            const int rho = min(16 * m + ((SMALL && m == MTN - 1) ? (lane & 3) : (lane & 15)), SBW * LL - 1);
             const int sm = rho / LL, pos = rho - sm * LL;
             ab[m] = ((hs + sm) * (LL + 4) + pos) * RS + kq4;
         }
@@ -361,9 +382,11 @@ __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* o
     zero_acc();
 #pragma unroll
     for (int m = 0; m < MT; ++m) racc[m] = f4{0.f, 0.f, 0.f, 0.f};
-    rows_k5(EDMP_IC(MT), L, RSX, ab);
+    constexpr int SM5 = Cf::small_tile(Cf::ROWS, MT) ? 1 : 0;  // the k5 stages at this level's length
+    rows_k5(EDMP_IC(MT), EDMP_IC(SM5), L, RSX, ab);
     if constexpr (NCH == 1) {
-        conv_stage(EDMP_IC(MT), EDMP_IC(6), EDMP_IC(6), EDMP_IC(0), P_K5RES, TX, RSX, KX / 16, p.w11, ab, bf);
+        conv_stage(EDMP_IC(MT), EDMP_IC(6), EDMP_IC(6), EDMP_IC(0), EDMP_IC(SM5), P_K5RES, TX, RSX, KX / 16, p.w11, ab, bf);
+        if constexpr (SM5 != 0) small_tile_finish(racc[MT - 1]);
     } else {
         constexpr int KGC = (KX / 16) / NCH;  // K groups per input chunk
         static_for<0, NCH>([&](auto cc) __attribute__((always_inline)) {
@@ -374,13 +397,17 @@ __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* o
 #pragma unroll
                 for (int u = 0; u < NITC; ++u) v[u] = in_load(nxt, u);
             }
-            conv_stage_range(EDMP_IC(MT), EDMP_IC(6), EDMP_IC(6), EDMP_IC(0), P_K5RES, TX, RSX, KX / 16, p.w11, ab, bf, c * KGC, (c + 1) * KGC);
+            conv_stage_range(EDMP_IC(MT), EDMP_IC(6), EDMP_IC(6), EDMP_IC(0), EDMP_IC(SM5), P_K5RES, TX, RSX, KX / 16, p.w11, ab, bf, c * KGC, (c + 1) * KGC);
             if constexpr (nxt < NCH) {
 #pragma unroll
                 for (int u = 0; u < NITC; ++u) in_commit(nxt, u, v[u]);
                 __syncthreads();
             }
         });
+        if constexpr (SM5 != 0) {
+            small_tile_finish(acc[MT - 1]);
+            small_tile_finish(racc[MT - 1]);
+        }
     }
     load_first(EDMP_IC(5), C / 16, p.w12, bf);
     EDMP_STAMP(LVSLOT, 2)
@@ -400,9 +427,9 @@ __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* o
         for (int i = tid; i < Cf::TF_FL / 4; i += 256) *reinterpret_cast<float4*>(TF + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     zero_acc();
-    rows_k5(EDMP_IC(MT), L, RSC, ab);
+    rows_k5(EDMP_IC(MT), EDMP_IC(SM5), L, RSC, ab);
     EDMP_STAMP(LVSLOT, 3)
-    conv_stage(EDMP_IC(MT), EDMP_IC(5), EDMP_IC(5), EDMP_IC(0), P_K5, TA, RSC, C / 16, p.w12, ab, bf);
+    conv_stage(EDMP_IC(MT), EDMP_IC(5), EDMP_IC(5), EDMP_IC(0), EDMP_IC(SM5), P_K5, TA, RSC, C / 16, p.w12, ab, bf);
     load_first(EDMP_IC(5), C / 16, p.w21, bf);
     EDMP_STAMP(LVSLOT, 4)
     {
@@ -413,7 +440,7 @@ __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* o
     EDMP_STAMP(LVSLOT, 5)
     // ================= RCB 2 (identity residual) =================
     zero_acc();
-    conv_stage(EDMP_IC(MT), EDMP_IC(5), EDMP_IC(5), EDMP_IC(0), P_K5, TB, RSC, C / 16, p.w21, ab, bf);
+    conv_stage(EDMP_IC(MT), EDMP_IC(5), EDMP_IC(5), EDMP_IC(0), EDMP_IC(SM5), P_K5, TB, RSC, C / 16, p.w21, ab, bf);
     load_first(EDMP_IC(5), C / 16, p.w22, bf);
     {  // TA is free: every wave passed the barrier behind RCB 1's conv2 epilogue; TB stays, it is the residual
         const float tbv = p.tb2[col];
@@ -421,7 +448,7 @@ __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* o
     }
     __syncthreads();
     zero_acc();
-    conv_stage(EDMP_IC(MT), EDMP_IC(5), EDMP_IC(5), EDMP_IC(0), P_K5, TA, RSC, C / 16, p.w22, ab, bf);
+    conv_stage(EDMP_IC(MT), EDMP_IC(5), EDMP_IC(5), EDMP_IC(0), EDMP_IC(SM5), P_K5, TA, RSC, C / 16, p.w22, ab, bf);
     if constexpr (MODE == LV_DOWN) load_first(EDMP_IC(3), C / 16, p.wrs, bf);
     else load_first(EDMP_IC(4), C / 16, p.wrs, bf);
     __syncthreads();  // TA is rewritten below with the block output
@@ -444,7 +471,7 @@ __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* o
             const int sm = rho / LOUT, lo = rho - sm * LOUT;
             ab[m] = ((hs + sm) * (L + 4) + 2 * lo + 1) * RSC + kq4;  // tap t reads input position 2 lo - 1 + t
         }
-        conv_stage(EDMP_IC(MTR), EDMP_IC(3), EDMP_IC(3), EDMP_IC(0), P_K5, TA, RSC, C / 16, p.wrs, ab, bf);
+        conv_stage(EDMP_IC(MTR), EDMP_IC(3), EDMP_IC(3), EDMP_IC(0), EDMP_IC(0), P_K5, TA, RSC, C / 16, p.wrs, ab, bf);
 #pragma unroll
         for (int m = 0; m < MTR; ++m)
 #pragma unroll
@@ -466,7 +493,7 @@ __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* o
             const int sm = idx / cnt, j = idx - sm * cnt;
             ab[m] = ((hs + sm) * (L + 4) + j + 1) * RSC + kq4;  // haloed row of input position j - 1
         }
-        conv_stage(EDMP_IC(MTR), EDMP_IC(4), EDMP_IC(4), EDMP_IC(MTE), P_UP, TA, RSC, C / 16, p.wrs, ab, bf);
+        conv_stage(EDMP_IC(MTR), EDMP_IC(4), EDMP_IC(4), EDMP_IC(MTE), EDMP_IC(0), P_UP, TA, RSC, C / 16, p.wrs, ab, bf);
         if constexpr (MODE == LV_UP_FINAL) load_first(EDMP_IC(5), C / 16, p.wfin, bf);
 #pragma unroll
         for (int m = 0; m < MTR; ++m)
@@ -488,7 +515,8 @@ __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* o
             constexpr int MTF = Cf::MTF;
             __syncthreads();
             zero_acc();
-            rows_k5(EDMP_IC(MTF), LOUT, RSC, ab);
+            constexpr int SMF = Cf::small_tile(SBW * LOUT, MTF) ? 1 : 0;
+            rows_k5(EDMP_IC(MTF), EDMP_IC(SMF), LOUT, RSC, ab);
             // fused tail (below): this thread's state / noise values are requested before the conv stage, they land under it
             double tail_x[8], tail_z[8];
             const int tail_sm = tid / LOUT, tail_pos = tid - tail_sm * LOUT;
@@ -504,7 +532,7 @@ __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* o
                     if (tid < 8) TW[8 * C + tid] = tid < p.tail.C ? p.tail.bias[tid] : 0.0f;
                 }
             }
-            conv_stage(EDMP_IC(MTF), EDMP_IC(5), EDMP_IC(5), EDMP_IC(0), P_K5, TF, RSC, C / 16, p.wfin, ab, bf);
+            conv_stage(EDMP_IC(MTF), EDMP_IC(5), EDMP_IC(5), EDMP_IC(0), EDMP_IC(SMF), P_K5, TF, RSC, C / 16, p.wfin, ab, bf);
             {
                 // ONE instance of the epilogue arithmetic for both destinations (two instances may be contracted differently by
                 // the compiler: the loop and the stepwise API would then differ in the last ulp).
