@@ -42,11 +42,12 @@ struct LevelCfg {
     static constexpr int MT = (ROWS + 15) / 16;
     // a last row tile with <= 4 real rows runs on v_mfma_f32_4x4x1_16B_f32 (16 blocks of 4x4, K = 1: the blocks = 4 column groups x the four
     // k of a fragment component; 10.5 cycles instead of 32, tools/mfma4x4_probe.hip): 50 rows cost 3 x 32 + 10.5 cycles per K step, not 128
-#ifdef EDMP_NO_SMALL_TILE
-    static constexpr bool small_tile(int rows, int mt) { return false && rows + mt > 0; }
+#ifdef EDMP_NO_SMALL_TILE  // (A/B builds: __graft_entry__._build_hip_library(("-DEDMP_NO_SMALL_TILE",)), profiles/r05_switch_ab.txt)
+    static constexpr bool kSmallTiles = false;
 #else
-    static constexpr bool small_tile(int rows, int mt) { return rows - 16 * (mt - 1) <= 4; }
+    static constexpr bool kSmallTiles = true;
 #endif
+    static constexpr bool small_tile(int rows, int mt) { return kSmallTiles && rows - 16 * (mt - 1) <= 4; }
     static constexpr int LOUT = (MODE == LV_DOWN) ? (L - 1) / 2 + 1 : ((2 * L == 8 || 2 * L == 14 || 2 * L == 26) ? 2 * L - 1 : 2 * L);
     static constexpr int NE = (LOUT + 1) / 2, NO = LOUT / 2;  // even / odd output positions of the transposed conv
     static constexpr int MTE = (SBW * NE + 15) / 16, MTO = (SBW * NO + 15) / 16;
