@@ -43,8 +43,8 @@ def measure(n_scenes=16, rows=1024, guides=(1, 2, 3, 4, 5, 10), n_obstacles=16, 
     }
     out = {"scenes": n_scenes, "rows_per_scene": rows, "guides": list(guides), "obstacles": n_obstacles, "true_cylinders": n_cylinders,
            "noise": "NumPy global RandomState per scene (the reference's contract), drawn by edmp_amd.nprng bit for bit",
-           "clock": "wall time of infer_serial.run's scene loop (the run's model build / upload excluded) over all scenes; steady_state_* = from the completion of "
-                    "scene k (k scenes in flight: pipeline full) to the last; per scene the reference's Planning Time split"}
+           "clock": "wall time of infer_serial.run's scene loop (the run's model build / upload excluded) over all scenes; steady_state_* = between the end of the first group of "
+                    "k scenes in flight and the end of the last (n - k scenes); per scene the reference's Planning Time split"}
     with tempfile.TemporaryDirectory() as td:
         os.makedirs(os.path.join(td, "configs"))
         path = os.path.join(td, "configs", "cfg_problem_set.yaml")
@@ -63,9 +63,11 @@ def measure(n_scenes=16, rows=1024, guides=(1, 2, 3, 4, 5, 10), n_obstacles=16, 
             torch.cuda.synchronize()
             wall = time.perf_counter() - t0 - infer_serial.run.last_setup_s  # (config parse, model build + upload: per run, not per scene)
             assert len(res) == n_scenes
-            # steady state: from the completion of scene k (the pipeline is full) to the last one
+            # steady state: scenes in flight finish in groups of k (they share the GPU from start to end), so the rate is taken between
+            # the END of the first group and the END of the last: n - k scenes in that interval (an interval that starts at the first
+            # completion of a group and ends at the last completion of another counts one group too many: +8 % at k = 2, n = 16)
             done = [r["done_at"] for r in res]
-            steady = (n_scenes - 1 - k) / (done[-1] - done[k]) if n_scenes > k + 1 else n_scenes / wall
+            steady = (n_scenes - k) / (done[-1] - done[k - 1]) if n_scenes > k else n_scenes / wall
             keys = sorted(res[0]["timings"])
             split = {key: float(np.mean([r["timings"][key] for r in res])) for key in keys}
             plan = float(np.mean([r["planning_time_s"] for r in res]))
@@ -86,8 +88,9 @@ def main():
     ap.add_argument("--rows", type=int, default=1024)
     ap.add_argument("--out", type=str, default=None)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--flights", type=str, default="1,2", help="scenes in flight to measure, e.g. 1,2,3")
     a = ap.parse_args()
-    out = measure(a.scenes, a.rows, verbose=a.verbose)
+    out = measure(a.scenes, a.rows, flights=tuple(int(k) for k in a.flights.split(",")), verbose=a.verbose)
     txt = json.dumps(out, indent=1)
     print(txt)
     if a.out:
