@@ -4,13 +4,17 @@ Values follow the reference's IntersectionVolumeGuide: modified-DH rows (lib/gui
 map (lib/guide.py:93-94, 286), static link-box frames (lib/guide.py:289-340), corner order (lib/guide.py:210-235)
 and the joint limits used to clip the guide input (diffusion/diffusion.py:282-296).
 
-Link-box extents: the reference measures them from pybullet_data's Franka collision meshes at run time
-(lib/guide.py:245-282); those meshes are not available offline, so `PLACEHOLDER_LINK_EXTENTS` is a documented
-stand-in and every API accepts the real (9,3) table as data (`link_mesh_extents=`).
+Link-box extents: the reference measures them from pybullet_data's Franka collision meshes every time a guide is
+built (lib/guide.py:245-282).  `link_extents_from_mesh_dir` is that reader; `resolve_link_extents` is the lookup order
+of every guide built here: an explicit (9,3) table, else a mesh directory (`mesh_dir=` / the run config's
+`model.mesh_dir`), else pybullet_data's directory when that package is importable, else `PLACEHOLDER_LINK_EXTENTS` - a
+documented stand-in for offline boxes - with ONE warning per process, because results then differ from the reference's.
 """
 from __future__ import annotations
 
 import math
+import os
+import warnings
 
 import numpy as np
 
@@ -99,6 +103,67 @@ PLACEHOLDER_LINK_EXTENTS = np.array(
     ],
     dtype=np.float64,
 )
+
+
+MESH_SUBDIR = os.path.join("franka_panda", "meshes", "collision")  # below pybullet_data.getDataPath() (lib/guide.py:245)
+
+
+def link_extents_from_mesh_dir(path) -> np.ndarray:
+    """(9, 3) float64 AABB extents (max - min over every vertex) of `<path>/{link1..7,hand,finger}.obj`, read the way
+    the reference does (lib/guide.py:245-269): a vertex is a line that, stripped, starts with 'v ' (so 'vn' / 'vt' / 'f' /
+    comments are skipped), its coordinates are the first three whitespace-separated fields after the 'v'.  The finger's
+    y x 4 (lib/guide.py:278-279) is NOT applied here: `link_half_extents` does that, for tables from any source."""
+    path = os.fspath(path)
+    ext = np.zeros((N_LINKS, 3), dtype=np.float64)
+    for i, name in enumerate(LINK_NAMES):
+        fn = os.path.join(path, name + ".obj")
+        if not os.path.isfile(fn):
+            raise FileNotFoundError(f"link mesh {fn} not found (expected {', '.join(n + '.obj' for n in LINK_NAMES)} in {path})")
+        verts = []
+        with open(fn, "r") as f:
+            for line in f:
+                line = line.strip()
+                if line.startswith("v "):
+                    verts.append([float(c) for c in line.split()[1:4]])
+        if not verts:
+            raise ValueError(f"{fn}: no vertex ('v x y z') lines")
+        v = np.array(verts, dtype=np.float64)
+        ext[i] = np.max(v, axis=0) - np.min(v, axis=0)
+    return ext
+
+
+_warned_placeholder = False
+
+
+def default_mesh_dir():
+    """pybullet_data's Franka collision-mesh directory if that package is importable (the reference's source,
+    lib/guide.py:245), else None."""
+    try:
+        import pybullet_data  # noqa: PLC0415 (optional third-party data package)
+    except Exception:
+        return None
+    d = os.path.join(pybullet_data.getDataPath(), MESH_SUBDIR)
+    return d if os.path.isdir(d) else None
+
+
+def resolve_link_extents(link_mesh_extents=None, mesh_dir=None) -> np.ndarray:
+    """The (9, 3) mesh-extent table a guide is built with: explicit table > `mesh_dir` > pybullet_data > placeholder (warns once)."""
+    global _warned_placeholder
+    if link_mesh_extents is not None:
+        ext = np.array(link_mesh_extents, dtype=np.float64)
+        if ext.shape != (N_LINKS, 3):
+            raise ValueError(f"link_mesh_extents must be (9, 3), got {ext.shape}")
+        return ext
+    if mesh_dir is None:
+        mesh_dir = os.environ.get("EDMP_MESH_DIR") or default_mesh_dir()
+    if mesh_dir is not None:
+        return link_extents_from_mesh_dir(mesh_dir)
+    if not _warned_placeholder:
+        _warned_placeholder = True
+        warnings.warn("edmp_amd: no Franka collision meshes found (pybullet_data not importable, no mesh_dir / model.mesh_dir / EDMP_MESH_DIR): "
+                      "link boxes use franka.PLACEHOLDER_LINK_EXTENTS - results differ from the reference's, which measures "
+                      "pybullet_data/franka_panda/meshes/collision/*.obj (lib/guide.py:245-282)", RuntimeWarning, stacklevel=3)
+    return PLACEHOLDER_LINK_EXTENTS.copy()
 
 
 def link_half_extents(link_mesh_extents=None) -> np.ndarray:

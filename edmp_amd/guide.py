@@ -42,11 +42,12 @@ class IntersectionVolumeGuide:
         guide.get_gradient(joint_input (B,7,48) ndarray, start, goal, t)  -> (B,7,48) f64 ndarray
         guide.choose_best_trajectory(start, goal, trajectories (B,7,50))  -> (7,50)
 
-    ``link_mesh_extents`` (9,3): AABB extents of the Franka collision meshes that the reference reads from
-    pybullet_data at run time (lib/guide.py:245-282); defaults to the documented placeholder table.
+    Link boxes: the reference measures the Franka collision meshes of pybullet_data every time a guide is built
+    (lib/guide.py:245-282).  Here (franka.resolve_link_extents): ``link_mesh_extents`` (9,3) if given, else the meshes in
+    ``mesh_dir``, else pybullet_data's directory when importable, else the placeholder table with one warning per process.
     """
 
-    def __init__(self, obstacle_config, device, guide_cfgs, batch_size, *, link_mesh_extents=None, obstacle_kinds=None):
+    def __init__(self, obstacle_config, device, guide_cfgs, batch_size, *, link_mesh_extents=None, mesh_dir=None, obstacle_kinds=None):
         self.ctx = get_context(device)
         self.device = self.ctx.device
         self.guide_cfgs = guide_cfgs
@@ -60,7 +61,8 @@ class IntersectionVolumeGuide:
         if clr.shape[0] != self.batch_size:
             raise ValueError(f"guide_cfgs rows ({clr.shape[0]}) != batch_size ({self.batch_size})")
         self.row_class, self._cls_clr, self._cls_exp = row_classes(clr, exp)
-        self._half = np.ascontiguousarray(franka.link_half_extents(link_mesh_extents))
+        self.link_mesh_extents = franka.resolve_link_extents(link_mesh_extents, mesh_dir)
+        self._half = np.ascontiguousarray(franka.link_half_extents(self.link_mesh_extents))
         self.link_dimensions = torch.from_numpy(self._half * 2)
         self._dh = np.ascontiguousarray(franka.dh_table())
         self._sf = np.ascontiguousarray(franka.static_frames())

@@ -235,7 +235,7 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=
                 # success check spawns the latter as true cylinders (infer_serial.py:159-163 -> lib/environment.py:249-268)
                 kinds = np.concatenate([np.zeros(int(num_cuboids), dtype=np.int32), np.ones(int(num_cylinders), dtype=np.int32)])
                 guide = IntersectionVolumeGuide(obstacle_config=obstacle_config, device=lanes[lane][0].ctx, guide_cfgs=guide_cfgs, batch_size=total_batch_size,
-                                                obstacle_kinds=kinds)
+                                                obstacle_kinds=kinds, mesh_dir=benchmark_cfg["model"].get("mesh_dir"))
                 t1 = time.time()
                 # IK-goal filter                                                              infer_serial.py:117-129
                 volumes = guide.cost(torch.tensor(all_ik_goals.reshape((-1, 7, 1))), 0, batch_size=all_ik_goals.shape[0]).sum(axis=(1, 2)).cpu().numpy()

@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C-ABI of libedmp_hip.so) against the CPU oracle and against the
 golden vectors captured from the unmodified reference.  Tolerances follow BASELINE.json's north star: joint-angle
 RMSE <= 1e-4 per step (teacher-forced); individual kernels are held to much tighter bounds."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -318,6 +320,35 @@ def test_gradient_golden(golden):
     cfg6 = cfgs_for([1, 2, 3, 4, 5, 10], 2)
     far6 = IntersectionVolumeGuide(g["scene_far"], DEV, cfg6, 12)
     assert np.isnan(far6.get_gradient(g["joints"], g["start"], g["goal"], 128)).all()
+
+
+def test_guide_built_from_a_mesh_directory(golden, oracle, tmp_path):
+    """a8: a guide whose link boxes were measured from .obj meshes (G15, the reference's reader) = a guide handed the same table,
+    and both follow the oracle built with that table (not the placeholder's boxes)."""
+    from edmp_amd import franka, scenes
+    from edmp_amd.guide import IntersectionVolumeGuide
+
+    g = golden("g15_link_meshes")
+    for name, text in zip(g["link_names"], g["obj_texts"]):
+        with open(os.path.join(str(tmp_path), str(name) + ".obj"), "w") as f:
+            f.write(str(text))
+    cfgs = cfgs_for([1, 10, 11], 2)
+    B = cfgs["total_batch_size"]
+    scene = scenes.random_scene(3, 8)
+    ga = IntersectionVolumeGuide(scene, DEV, cfgs, B, mesh_dir=str(tmp_path))
+    assert np.array_equal(ga.link_dimensions.numpy(), g["link_dimensions"])
+    gb = IntersectionVolumeGuide(scene, DEV, cfgs, B, link_mesh_extents=franka.link_extents_from_mesh_dir(tmp_path))
+    gp = IntersectionVolumeGuide(scene, DEV, cfgs, B, link_mesh_extents=franka.PLACEHOLDER_LINK_EXTENTS)
+    og = oracle.GuideOracle(scene, cfgs, B, link_mesh_extents=ga.link_mesh_extents)
+    rs = np.random.RandomState(5)
+    lo, hi = oracle.joint_limits()
+    q = rs.uniform(lo[None, :, None], hi[None, :, None], (B, 7, 48))
+    s, gl = scenes.random_start_goal(9)
+    a, b, c = (x.get_gradient(q, s, gl, 100) for x in (ga, gb, gp))
+    assert np.array_equal(a, b)
+    assert not np.array_equal(a, c)
+    o = og.get_gradient(q, s, gl, 100)
+    assert maxabs(a, o) <= 5e-5 and rmse(a, o) <= 3e-6, (maxabs(a, o), rmse(a, o))
 
 
 def test_gradient_vs_oracle_random(oracle):
