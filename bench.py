@@ -24,6 +24,7 @@ import torch.distributed as dist  # noqa: E402
 T, N, C = 255, 50, 7
 FULL_DIMS = (32, 64, 128, 256, 512, 512)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense bf16 MFMA peak (16 x the fp32 rate; no sparsity)
 SURVEY_FLOPS_PER_TRAJ_STEP = 187_339_904
 
 
@@ -73,6 +74,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true", help="skip the instrumented (HIP-event) pass")
     ap.add_argument("--cpu-steps", type=int, default=16, help="reverse steps of the bounded CPU-baseline sample")
     ap.add_argument("--no-two-scenes", action="store_true", help="skip the informative two-scenes-in-flight measurement")
+    ap.add_argument("--no-native-leg", action="store_true", help="skip the A/B leg with every conv on the fp32-MFMA kernels (value_native_f32)")
     ap.add_argument("--no-problem-set", action="store_true", help="skip the informative problem-set measurement (16 distinct scenes through infer_serial.run)")
     ap.add_argument("--chains", type=int, default=int(os.environ.get("EDMP_CHAINS", "1")),
                     help="run the one batch as this many row-sharded chains on separate HIP streams (edmp_sampler_set_chains; bit-identical results)")
@@ -193,9 +195,45 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} but the process group summed {n_ranks_seen} ranks")
     value = world * B * T * args.steps / dt
 
+    # ---- A/B leg (round 6): the same workload with EVERY conv on the fp32-MFMA kernels (EDMP_BF16X3=0 at model-build time) --------
+    # `value` is the default product path: 13 of the 40 conv launches of a reverse step form each fp32 product as six exact bf16
+    # partial products on the bf16 matrix pipe, fp32 accumulation (csrc/bf3.hip) - measured at HALF the fp32-MFMA kernels' error
+    # against float64 (profiles/r06_bf16x3.md, tests: test_bf16x3_split_layers_...).  The native leg keeps the two numbers side by side.
+    native = None
+    if not args.no_native_leg:
+        env_prev = os.environ.get("EDMP_BF16X3")
+        os.environ["EDMP_BF16X3"] = "0"
+        try:
+            net_n = TemporalUNet(None, C, 32, dev, dims=FULL_DIMS, seed=1, max_batch=B)
+        finally:
+            if env_prev is None:
+                del os.environ["EDMP_BF16X3"]
+            else:
+                os.environ["EDMP_BF16X3"] = env_prev
+        net_default, n_steps_native = net, max(1, min(args.steps, 5))
+        net = net_n
+        try:
+            one_call()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(n_steps_native):
+                one_call()
+            barrier()
+            dtn = time.perf_counter() - t0
+        finally:
+            net = net_default
+        if world > 1:
+            ttn = torch.tensor([dtn], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(ttn, op=dist.ReduceOp.MAX)
+            dtn = float(ttn.item())
+        native = {"value": world * B * T * n_steps_native / dtn, "ms_per_step": 1e3 * dtn / n_steps_native, "steps": n_steps_native, "warmup": 1}
+        del net_n
+        one_call()  # re-bind the default model (resident slot): the instrumented passes below read ITS layer program
+
     out = None
     if rank == 0:
         nominal, executed = net.flops_per_trajectory()
+        f32_bf16 = net.flops_by_pipe()
         out = {
             "metric": "guided denoise-steps/sec (trajectories x reverse steps)",
             "value": value,
@@ -210,6 +248,12 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            "dtype_variant": (None if f32_bf16[1] == 0 else "f32 results, fp32 accumulation; the Conv1dBlocks at L=13 / L=7 (13 of 40 conv launches per reverse step) form every fp32 product as six "
+                              "EXACT bf16 x bf16 partial products on the bf16 matrix pipe (bf16x3 split, csrc/bf3.hip); error vs float64 0.36-0.75 x the fp32-MFMA kernels' "
+                              "(profiles/r06_bf16x3.md); EDMP_BF16X3=0 selects the all-fp32-MFMA program = value_native_f32"),
+            "value_bf16x3": (value if f32_bf16[1] > 0 else None),
+            "value_native_f32": (value if f32_bf16[1] == 0 else (native["value"] if native else None)),
+            "native_f32_leg": native,
             "data": "synthetic",
             "config": {
                 "workload": f"denoise_guided T={T} N={N} batch={B}/GPU, {len(guides)}-guide ensemble {guides}, {args.obstacles}-cuboid synthetic scene, full TemporalUNet (29.9M params, random init), f64 state / f32 denoiser+guide",
@@ -232,8 +276,10 @@ def main():
             # all-reduce of sum(g^2) on the context's stream), rank 0, last call
             "allreduce_hook": (None if not logical else {"calls_per_denoise": dif.hook_stats["calls"], "avg_us": 1e6 * dif.hook_stats["total_s"] / max(dif.hook_stats["calls"], 1),
                                                         "max_us": 1e6 * dif.hook_stats["max_s"]}),
-            "unet_flops_per_traj_step": {"nominal": nominal, "direct_form_after_tap_skipping": net.flops_direct_form(), "issued_mfma": executed, "survey": SURVEY_FLOPS_PER_TRAJ_STEP,
-                                         "note": "issued < direct form: the L=2 / L=4 Conv1dBlocks run in Karatsuba form (3 of 4 resp. 9 of 14 matrix products)"},
+            "unet_flops_per_traj_step": {"nominal": nominal, "direct_form_after_tap_skipping": net.flops_direct_form(), "issued_mfma_fp32_equivalent": executed,
+                                         "issued_on_the_fp32_pipe": f32_bf16[0], "issued_on_the_bf16_pipe": f32_bf16[1], "survey": SURVEY_FLOPS_PER_TRAJ_STEP,
+                                         "note": "issued (fp32 equivalent) < direct form: the L=2 / L=4 Conv1dBlocks run in Karatsuba form (3 of 4 resp. 9 of 14 matrix products); the bf16x3 layers "
+                                                 "issue 6 bf16 MFMA FLOPs per fp32 FLOP they replace, on the bf16 pipe"},
         }
 
     # ---- cost of the success kernel: on the batch just produced (random-init rows collide early and leave the obstacle loop at the
@@ -352,7 +398,10 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
         import problem_set_bench
 
-        out["problem_set"] = problem_set_bench.measure(16, B, tuple(guides), args.obstacles, min(3, args.obstacles), device=dev)
+        try:  # informative leg: a failure here (pinned allocation, config) must not lose the measured line
+            out["problem_set"] = problem_set_bench.measure(16, B, tuple(guides), args.obstacles, min(3, args.obstacles), device=dev)
+        except Exception as exc:  # noqa: BLE001
+            out["problem_set"] = {"error": f"{type(exc).__name__}: {exc}"}
 
     # ---- roofline of the dominant kernel family (fp32-MFMA conv kernels of the UNet), N=1 only ----------------------
     # Two extra, instrumented calls with HIP events on the context's stream:
@@ -376,59 +425,79 @@ def main():
         ctx.prof(1)
         one_call()
         ops = ctx.prof_ops()
+        ops_bf16 = ctx.prof_ops_bf16()
         ev_ms, launches_b = ctx.prof_read(reset=True)
         ctx.prof(0)
         ms_step = 1e3 * dt / args.steps
         over_us = 1e3 * (ev_ms - conv_ms) / max(launches_b, 1)  # event overhead per bracketed launch in pass B
         nominal, executed = net.flops_per_trajectory()
+        f32_issued, bf16_issued = net.flops_by_pipe()
         head = 2.0 * N * C * FULL_DIMS[0]  # the 1x1 head runs inside the (VALU) posterior kernel
         conv_nominal, conv_exec = nominal - head, executed - head
+        f32_issued -= head
         table = {}
-        for name, calls, ms, fl in ops:
+        for (name, calls, ms, fl), fb in zip(ops, ops_bf16):
             if calls == 0:
                 continue
-            r = table.setdefault(name, {"launches": 0, "ms": 0.0, "flop": 0.0})
+            r = table.setdefault(name, {"launches": 0, "ms": 0.0, "flop": 0.0, "flop_bf16": 0.0})
             r["launches"] += calls
             r["ms"] += max(ms - 1e-3 * over_us * calls, 0.0)
             r["flop"] += fl * B * calls
+            r["flop_bf16"] += fb * B * calls
         rows = []
         for name, r in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
             tf = r["flop"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
-            rows.append({"kernel": name, "launches": r["launches"], "avg_us": 1e3 * r["ms"] / r["launches"], "share": r["ms"] / conv_ms if conv_ms else 0.0,
-                         "executed_tflops": tf, "frac": tf / PEAK_F32_MFMA_TFLOPS})
+            row = {"kernel": name, "launches": r["launches"], "avg_us": 1e3 * r["ms"] / r["launches"], "share": r["ms"] / conv_ms if conv_ms else 0.0}
+            if r["flop_bf16"] > 0:  # a bf16x3 kernel: its matrix work is issued on the bf16 pipe; `executed_tflops` stays the fp32 work it REPLACES
+                tb16 = r["flop_bf16"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
+                row.update({"pipe": "bf16", "issued_tflops": tb16, "frac": tb16 / PEAK_BF16_MFMA_TFLOPS, "fp32_equivalent_tflops": tf, "fp32_equivalent_vs_fp32_peak": tf / PEAK_F32_MFMA_TFLOPS})
+            else:
+                row.update({"pipe": "f32", "executed_tflops": tf, "frac": tf / PEAK_F32_MFMA_TFLOPS})
+            rows.append(row)
         conv_direct = net.flops_direct_form() - head
-        ach = conv_exec * B * T / (conv_ms * 1e-3) / 1e12
-        ach_direct = conv_direct * B * T / (conv_ms * 1e-3) / 1e12
+        t_conv = conv_ms * 1e-3
+        # matrix-pipe time at peak of one call: every kernel's issued work on ITS pipe at that pipe's dense peak
+        pipe_s = (f32_issued / (PEAK_F32_MFMA_TFLOPS * 1e12) + bf16_issued / (PEAK_BF16_MFMA_TFLOPS * 1e12)) * B * T
+        issued_total = (f32_issued + bf16_issued) * B * T
+        ach = issued_total / t_conv / 1e12
+        peak_eff = issued_total / pipe_s / 1e12  # the rate this mix of fp32- and bf16-pipe work would run at if every kernel sat on its roof
+        ach_direct = conv_direct * B * T / t_conv / 1e12
         tb = traffic_bytes_per_launch(pmc_traffic())
         avg_s = 1e-3 * conv_ms / max(launches, 1)
         out["roofline"] = {
-            "kernel": "fp32-MFMA conv family of the TemporalUNet: edmp::wide_conv_kernel (position-tile Conv1d k5 + GroupNorm + Mish, k3s2, ConvTranspose k4s2; "
-                      "128..512 channels) + edmp::level_kernel (whole 32/64-channel levels: two residual blocks + resampling conv per launch)",
+            "kernel": "MFMA conv family of the TemporalUNet: edmp::wide_conv_kernel (position-tile Conv1d k5 + GroupNorm + Mish, k3s2, ConvTranspose k4s2; fp32 MFMA, Karatsuba forms at L=2/4) + "
+                      "edmp::bf3_conv_kernel (the same op at L=13 / L=7 as six exact bf16 partial products per fp32 product on the bf16 pipe, fp32 accumulation) + "
+                      "edmp::level_kernel (whole 32/64-channel levels, fp32 MFMA)",
             "bound": "mfma",
             "achieved": ach,
-            "peak": PEAK_F32_MFMA_TFLOPS,
+            "peak": peak_eff,
             "unit": "TFLOP/s",
-            "frac": ach / PEAK_F32_MFMA_TFLOPS,
-            "flops": "MFMA work actually issued (padding taps never issued; Karatsuba forms at L=2/L=4 issue 3 of 4 / 9 of 14 products): matrix-pipe utilisation",
-            # the same time against the direct form's FLOPs with padding taps skipped - the figure round 1's review computed (0.53 there)
+            "frac": ach / peak_eff,
+            "flops": "MFMA work actually ISSUED, each kernel on its own pipe (fp32: padding taps never issued, Karatsuba forms at L=2/L=4 issue 3 of 4 / 9 of 14 products; bf16x3 kernels: 6 x the "
+                     "direct form, on the bf16 pipe).  peak = issued work / (fp32-pipe work / 157.3 + bf16-pipe work / 2516.6 TFLOP/s): frac = matrix-pipe time at peak / measured time",
+            "pipes": {"f32": {"issued_flop_per_traj_step": f32_issued, "peak_tflops": PEAK_F32_MFMA_TFLOPS, "pipe_ms_at_peak_per_call": 1e3 * f32_issued * B * T / (PEAK_F32_MFMA_TFLOPS * 1e12)},
+                      "bf16": {"issued_flop_per_traj_step": bf16_issued, "peak_tflops": PEAK_BF16_MFMA_TFLOPS, "pipe_ms_at_peak_per_call": 1e3 * bf16_issued * B * T / (PEAK_BF16_MFMA_TFLOPS * 1e12)}},
+            # the same time against the fp32 work the program REPLACES (direct form, padding taps skipped) and the fp32 pipe's peak: what an all-fp32-MFMA program would need to reach
             "achieved_direct_form": ach_direct,
             "frac_direct_form": ach_direct / PEAK_F32_MFMA_TFLOPS,
+            "achieved_fp32_equivalent_issued": conv_exec * B * T / t_conv / 1e12,
+            "frac_fp32_equivalent_issued_vs_fp32_peak": conv_exec * B * T / t_conv / 1e12 / PEAK_F32_MFMA_TFLOPS,
             "traffic": tb,  # HBM bytes per conv launch (PMC FETCH_SIZE x2 + WRITE_SIZE passes, committed under profiles/)
             "traffic_detail": pmc_traffic(),
             # north-star asks for the HBM fraction too: PMC bytes per launch / average launch duration vs 8 TB/s
             "hbm": None if tb is None else {"achieved": tb / avg_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": tb / avg_s / 1e9 / 8000.0},
-            "achieved_nominal": conv_nominal * B * T / (conv_ms * 1e-3) / 1e12,
+            "achieved_nominal": conv_nominal * B * T / t_conv / 1e12,
             "launches": launches,
             "avg_launch_us": 1e3 * conv_ms / max(launches, 1),
-            "flops_per_launch_issued": conv_exec * B * T / max(launches, 1),
+            "flops_per_launch_issued": issued_total / max(launches, 1),
             "conv_ms_per_call": conv_ms,
             "conv_share_of_step": conv_ms / ms_step,
             "timing": {"ms_per_step_timed": ms_step, "passA_program_brackets_conv_ms": conv_ms, "passA_wall_ms": passA_wall_ms, "passB_per_launch_brackets_ms": ev_ms,
                        "passB_event_overhead_us_per_launch": over_us},
             "per_kernel": rows,
-            "note": "achieved = executed conv FLOPs of one denoise_guided call / conv_ms_per_call (one HIP-event pair around each reverse step's layer program: "
+            "note": "achieved = issued MFMA FLOPs of one denoise_guided call / conv_ms_per_call (one HIP-event pair around each reverse step's layer program: "
                     "includes the inter-kernel dispatch gaps, like rocprofv3's back-to-back kernel trace); per_kernel rows = per-launch brackets minus the measured "
-                    "event overhead per launch; achieved_nominal counts every tap (SURVEY 8d)",
+                    "event overhead per launch, each against its own pipe's peak; achieved_nominal counts every tap (SURVEY 8d)",
         }
 
     # ---- CPU baseline: the oracle (port of the reference) on this box's host cores, bounded sample -----------------

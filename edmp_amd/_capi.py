@@ -78,6 +78,8 @@ SIGNATURES = {
     "edmp_unet_read_packed": (_i, [_vp, _pf, C.c_int64]),
     "edmp_unet_load_packed": (_i, [_vp, C.POINTER(UNetDesc), _pf, C.c_int64, _i, _i]),
     "edmp_unet_flops_direct": (_i, [_vp, _pd]),
+    "edmp_unet_flops_pipes": (_i, [_vp, _pd, _pd]),
+    "edmp_prof_ops_bf16": (_i, [_vp, _i, C.POINTER(C.c_int), _pd]),
     "edmp_unet_slot": (_i, [_vp, C.c_uint64]),
     "edmp_guide_slot": (_i, [_vp, C.c_uint64]),
     "edmp_argmin_dev": (_i, [_vp, _vp, _i, C.POINTER(C.c_int)]),

@@ -1,4 +1,4 @@
-// kernel_instances.h — every instance of the position-tile kernel (wide.hip) and of the whole-level kernel (level.hip)
+// kernel_instances.h — every instance of the position-tile kernels (wide.hip, bf3.hip) and of the whole-level kernel (level.hip)
 // the layer program can launch (unet.hip: launch_rcb / launch_wrs / launch_level), with the build shard that compiles it.
 // The sharded build (__graft_entry__.build) compiles kernel_shard.hip once per shard in parallel (one instance takes
 // 3-30 s of compile time, the lot in one translation unit a quarter of an hour); the core translation unit only sees
@@ -38,6 +38,21 @@
     X(12, WK_DOWN, 16, 64, 64, 4, false)  \
     X(13, WK_UP, 16, 64, 64, 2, false)
 
+// X(shard, KIND, MS, CG, GS, LIN, RES): the bf16x3 position-tile kernel (bf3.hip)
+#define EDMP_BF3_INSTANCES(X)            \
+    X(16, WK_K5, 32, 32, 32, 7, true)    \
+    X(17, WK_K5, 32, 32, 32, 7, false)   \
+    X(18, WK_K5, 16, 32, 16, 7, true)    \
+    X(16, WK_K5, 16, 32, 16, 7, false)   \
+    X(17, WK_K5, 16, 32, 16, 13, true)   \
+    X(18, WK_K5, 16, 32, 16, 13, false)  \
+    X(16, WK_DOWN, 32, 32, 32, 7, false) \
+    X(17, WK_UP, 32, 32, 32, 4, false)   \
+    X(18, WK_DOWN, 32, 32, 32, 4, false) \
+    X(16, WK_UP, 32, 32, 32, 2, false)   \
+    X(17, WK_DOWN, 16, 32, 16, 13, false) \
+    X(18, WK_UP, 16, 32, 16, 7, false)
+
 // X(shard, MODE, C, L, SB, CIN)
 #define EDMP_LEVEL_INSTANCES(X)        \
     X(8, LV_DOWN, 32, 50, 4, 8)        \
@@ -54,4 +69,4 @@
     X(14, LV_DOWN, 32, 50, 8, LV_DOWN, 64, 25, 32, 2) \
     X(15, LV_UP, 64, 13, 256, LV_UP_FINAL, 32, 25, 128, 2)
 
-#define EDMP_KERNEL_SHARDS 16
+#define EDMP_KERNEL_SHARDS 19

@@ -3,6 +3,7 @@
 #include "common.h"
 #include "params.h"
 #include "wide.hip"
+#include "bf3.hip"
 #include "level.hip"
 #include "kernel_instances.h"
 
@@ -13,6 +14,7 @@
 namespace edmp {
 // instantiate the entries whose shard number is EDMP_SHARD
 #define EDMP_X(sh, K, MS, CG, GS, L, R) EDMP_IF_SHARD(sh, template int launch_wide_t<K, MS, CG, GS, L, R>(const RcbP&, hipStream_t);)
+#define EDMP_W(sh, K, MS, CG, GS, L, R) EDMP_IF_SHARD(sh, template int launch_bf3_t<K, MS, CG, GS, L, R>(const RcbP&, hipStream_t);)
 #define EDMP_Y(sh, M, C, L, SB, CIN) EDMP_IF_SHARD(sh, template int launch_level_t<M, C, L, SB, CIN>(const LevelP&, hipStream_t);)
 #define EDMP_Z(sh, MA, CA, LA, CINA, MB, CB, LB, CINB, SB) EDMP_IF_SHARD(sh, template int launch_level2_t<MA, CA, LA, CINA, MB, CB, LB, CINB, SB>(const LevelP&, const LevelP&, hipStream_t);)
 #define EDMP_IF_SHARD(sh, ...) EDMP_IF_SHARD_I(sh, __VA_ARGS__)
@@ -33,6 +35,9 @@ namespace edmp {
 #define EDMP_SHARD_13(...)
 #define EDMP_SHARD_14(...)
 #define EDMP_SHARD_15(...)
+#define EDMP_SHARD_16(...)
+#define EDMP_SHARD_17(...)
+#define EDMP_SHARD_18(...)
 #if EDMP_SHARD == 0
 #undef EDMP_SHARD_0
 #define EDMP_SHARD_0(...) __VA_ARGS__
@@ -81,10 +86,20 @@ namespace edmp {
 #elif EDMP_SHARD == 15
 #undef EDMP_SHARD_15
 #define EDMP_SHARD_15(...) __VA_ARGS__
+#elif EDMP_SHARD == 16
+#undef EDMP_SHARD_16
+#define EDMP_SHARD_16(...) __VA_ARGS__
+#elif EDMP_SHARD == 17
+#undef EDMP_SHARD_17
+#define EDMP_SHARD_17(...) __VA_ARGS__
+#elif EDMP_SHARD == 18
+#undef EDMP_SHARD_18
+#define EDMP_SHARD_18(...) __VA_ARGS__
 #else
 #error "EDMP_SHARD out of range"
 #endif
 EDMP_WIDE_INSTANCES(EDMP_X)
+EDMP_BF3_INSTANCES(EDMP_W)
 EDMP_LEVEL_INSTANCES(EDMP_Y)
 EDMP_LEVEL2_INSTANCES(EDMP_Z)
 }  // namespace edmp

@@ -132,12 +132,14 @@ struct Op {
     int rc_L;     // OP_RCB / OP_WRS: input positions
     int rc_form;  // OP_RCB: 0 direct | 2 / 4 Karatsuba form at L = 2 / 4 (decided when the model was built)
     int rc_ms;    // OP_RCB / OP_WRS: samples per workgroup (wide_ms, frozen at build time)
+    int rc_bf3;   // OP_RCB / OP_WRS: 1 = runs on the bf16 matrix pipe with exact products (bf3.hip; bf3_select, frozen at build time)
     int wrs_kind; // OP_WRS: WK_DOWN / WK_UP
     int tb_off;   // GN: offset into the time-bias row, -1 if none
     int branch;   // 0 = main stream; 1 = fork point (record before this op); 2 = runs on the side stream; 3 = join (wait) before this op
 
     double flops_nominal, flops_exec;  // per trajectory: every tap | MFMA work actually issued (padding taps skipped, Karatsuba forms)
     double flops_direct;               // per trajectory: the direct form with padding taps skipped (round-1 'executed' accounting)
+    double flops_bf16;                 // per trajectory: MFMA work issued on the bf16 pipe (bf3.hip ops: 6 partial products x the direct form; else 0)
     char name[64];                     // kernel instance as rocprofv3 prints it (without the edmp:: prefix)
 };
 
@@ -160,6 +162,7 @@ struct UNet {
     struct Tap { int which; const float* p; int C, L; };
     std::vector<Tap> taps;
     double flops_nominal = 0, flops_exec = 0, flops_direct = 0;
+    double flops_bf16 = 0, flops_f32_moved = 0;  // issued on the bf16 pipe | the fp32 work (direct form) those ops replace
     int layout = 0;  // layout id of the packed weight image (Packer::layout_id)
     bool fuse_tail = true;  // EDMP_NO_FUSED_TAIL at build time
 };
@@ -384,12 +387,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
 
 }  // namespace edmp
 #include "wide.hip"
+#include "bf3.hip"
 #include "level.hip"
 #ifdef EDMP_SHARDED  // the position-tile and whole-level kernels are compiled in parallel translation units (kernel_shard.hip)
 #include "kernel_instances.h"
 namespace edmp {
 #define EDMP_X(sh, K, MS, CG, GS, L, R) extern template int launch_wide_t<K, MS, CG, GS, L, R>(const RcbP&, hipStream_t);
 EDMP_WIDE_INSTANCES(EDMP_X)
+#undef EDMP_X
+#define EDMP_X(sh, K, MS, CG, GS, L, R) extern template int launch_bf3_t<K, MS, CG, GS, L, R>(const RcbP&, hipStream_t);
+EDMP_BF3_INSTANCES(EDMP_X)
 #undef EDMP_X
 #define EDMP_X(sh, M, C, L, SB, CIN) extern template int launch_level_t<M, C, L, SB, CIN>(const LevelP&, hipStream_t);
 EDMP_LEVEL_INSTANCES(EDMP_X)
@@ -587,9 +594,41 @@ static int ms16_mask() {
     const char* e = getenv("EDMP_MS16");
     return e ? (int)strtol(e, nullptr, 0) : kMs16Default;
 }
+// bf16x3 split (bf3.hip): the direct-form instances whose weights meet >= 7 positions run on the bf16 matrix pipe with exact
+// products and fp32 accumulation - measured x1.2-1.55 per launch at HALF the fp32-MFMA kernel's error against float64
+// (profiles/r06_bf16x3.md).  EDMP_BF16X3=<mask> (read at model-build time, frozen into the layer program and the packed image's
+// layout id): bit 0 Conv1dBlock L = 7 / 256 ch, bit 1 Conv1dBlock L = 7 / 128 ch, bit 2 Conv1dBlock L = 13 / 128 ch,
+// bit 3 the k3s2 (L = 7) / ConvTranspose (L = 4) resamplers at 256 channels, bit 4 those at 512 channels (L = 4 / L = 2), bit 5 those at
+// 128 channels (L = 13 / L = 7).  0 = every conv on the fp32-MFMA kernels (bench.py's A/B leg).
+static const int kBf3Default = 0x3f;  // same-box bench A/B (profiles/r06_bf16x3.md): 0 -> 1 001 k, 0x7 -> 1 083 k, 0xf 1 091 k, 0x17 1 097 k, 0x27 1 086 k, 0x3f -> 1 102 k traj-steps/s
+static int bf3_mask() {
+    const char* e = getenv("EDMP_BF16X3");
+    return e ? (int)strtol(e, nullptr, 0) : kBf3Default;
+}
+// kind: WK_K5 (a Conv1dBlock; L = its length), WK_DOWN / WK_UP (L = input length)
+static bool bf3_select(int cout, int L, int kind) {
+    const int cg = cout / 8, m = bf3_mask();
+    if (kind == WK_K5) {
+        if (cg == 32 && L == 7) return m & 1;
+        if (cg == 16 && L == 7) return m & 2;
+        if (cg == 16 && L == 13) return m & 4;
+    }
+    if (kind == WK_DOWN) {
+        if (cg == 32 && L == 7) return m & 8;
+        if (cg == 64 && L == 4) return m & 16;
+        if (cg == 16 && L == 13) return m & 32;
+    }
+    if (kind == WK_UP) {
+        if (cg == 32 && L == 4) return m & 8;
+        if (cg == 64 && L == 2) return m & 16;
+        if (cg == 16 && L == 7) return m & 32;
+    }
+    return false;
+}
 // kind: WK_K5 (a Conv1dBlock; L = its length), WK_DOWN / WK_UP (L = input length)
 static int wide_ms(int cout, int L, int kind) {
     const int cg = cout / 8;
+    if (bf3_select(cout, L, kind)) return cg >= 32 ? 32 : 16;  // bf3.hip: 32-sample workgroups at 256 channels (256 workgroups), 16 at 128
     if (cg < 32) return 16;
     if (kind == WK_K5 && rcb_form(cout, L) != 0) return 32;
     const int m = ms16_mask();
@@ -600,9 +639,19 @@ static int wide_ms(int cout, int L, int kind) {
     if (kind == WK_UP && cg == 64 && L == 2) return (m & 16) ? 16 : 32;
     return 32;
 }
-static int launch_rcb(const RcbP& p, int L, int form, int ms, hipStream_t s) {
+static int launch_rcb(const RcbP& p, int L, int form, int ms, int bf3, hipStream_t s) {
     const int cg = p.Cout / 8;
     const bool res = p.res_out != nullptr;
+    if (bf3) {
+#define EDMP_B3(MS, GS, LL) \
+    return res ? launch_bf3_t<WK_K5, MS, 32, GS, LL, true>(p, s) : launch_bf3_t<WK_K5, MS, 32, GS, LL, false>(p, s);
+        if (cg == 32 && L == 7) { EDMP_B3(32, 32, 7) }
+        if (cg == 16 && L == 7) { EDMP_B3(16, 16, 7) }
+        if (cg == 16 && L == 13) { EDMP_B3(16, 16, 13) }
+#undef EDMP_B3
+        set_error("no bf16x3 conv+GroupNorm kernel for Cout=%d L=%d", p.Cout, L);
+        return EDMP_ERR_STATE;
+    }
 #define EDMP_K5(MS, CG, GS, LL) \
     return res ? launch_wide_t<WK_K5, MS, CG, GS, LL, true>(p, s) : launch_wide_t<WK_K5, MS, CG, GS, LL, false>(p, s);
     if (cg == 64 && L == 2) {
@@ -704,8 +753,18 @@ static bool wrs_supported(int cout, int cin, int Lin, bool transposed) {
     if (transposed) return (cg == 64 && Lin == 2) || (cg == 32 && Lin == 4) || (cg == 16 && Lin == 7);
     return (cg == 64 && Lin == 4) || (cg == 32 && Lin == 7) || (cg == 16 && Lin == 13);
 }
-static int launch_wrs(const RcbP& p, int kind, int Lin, int ms, hipStream_t s) {
+static int launch_wrs(const RcbP& p, int kind, int Lin, int ms, int bf3, hipStream_t s) {
     const int cg = p.Cout / 8;
+    if (bf3) {  // bf3.hip: no GroupNorm behind a resampler, so 32-channel workgroups at every width
+        if (kind == WK_DOWN && cg == 32 && Lin == 7) return launch_bf3_t<WK_DOWN, 32, 32, 32, 7, false>(p, s);
+        if (kind == WK_UP && cg == 32 && Lin == 4) return launch_bf3_t<WK_UP, 32, 32, 32, 4, false>(p, s);
+        if (kind == WK_DOWN && cg == 64 && Lin == 4) return launch_bf3_t<WK_DOWN, 32, 32, 32, 4, false>(p, s);
+        if (kind == WK_UP && cg == 64 && Lin == 2) return launch_bf3_t<WK_UP, 32, 32, 32, 2, false>(p, s);
+        if (kind == WK_DOWN && cg == 16 && Lin == 13) return launch_bf3_t<WK_DOWN, 16, 32, 16, 13, false>(p, s);
+        if (kind == WK_UP && cg == 16 && Lin == 7) return launch_bf3_t<WK_UP, 16, 32, 16, 7, false>(p, s);
+        set_error("no bf16x3 resampling kernel for kind=%d Cout=%d Lin=%d", kind, p.Cout, Lin);
+        return EDMP_ERR_STATE;
+    }
     if (ms == 16 && cg >= 32) {  // 16-sample tiles at 256 / 512 channels (wide_ms)
         if (kind == WK_DOWN && cg == 32 && Lin == 7) return launch_wide_t<WK_DOWN, 16, 32, 32, 7, false>(p, s);
         if (kind == WK_UP && cg == 32 && Lin == 4) return launch_wide_t<WK_UP, 16, 32, 32, 4, false>(p, s);
@@ -731,7 +790,9 @@ static void op_kernel_name(const Op& op, char* out) {
     if (op.kind == OP_RCB || op.kind == OP_WRS) {
         const int cg = op.rc.Cout / 8, ms = op.rc_ms;
         const int kind = op.kind == OP_RCB ? (op.rc_form == 2 ? 3 : op.rc_form == 4 ? 4 : 0) : op.wrs_kind;
-        snprintf(out, 64, "wide_conv_kernel<%d, %d, %d, %d, %d, %s>", kind, ms, cg < 32 ? 32 : cg, cg, op.rc_L,
+        if (op.rc_bf3 && op.kind == OP_WRS) snprintf(out, 64, "bf3_conv_kernel<%d, %d, 32, %d, %d, false>", kind, ms, cg < 32 ? 16 : 32, op.rc_L);
+        else
+        snprintf(out, 64, "%s_conv_kernel<%d, %d, %d, %d, %d, %s>", op.rc_bf3 ? "bf3" : "wide", kind, ms, cg < 32 ? 32 : cg, cg, op.rc_L,
                  (op.kind == OP_RCB && op.rc.res_out) ? "true" : "false");
     }
     else if (op.kind == OP_LVL && op.lv_merge) snprintf(out, 64, op.lv_variant == 1 ? "level2_kernel<0, 32, 50, 8, 0, 64, 25, 32, 2>" : "level2_kernel<1, 64, 13, 256, 2, 32, 25, 128, 2>");
@@ -782,7 +843,7 @@ struct Packer {
             sig *= 1099511628211ull;
         }
     }
-    enum Form : uint64_t { F_CONV = 1, F_CONVT = 2, F_FRAG = 3, F_FRAG_K2 = 4, F_FRAG_K4 = 5, F_RESAMPLE = 6, F_VEC = 7 };
+    enum Form : uint64_t { F_CONV = 1, F_CONVT = 2, F_FRAG = 3, F_FRAG_K2 = 4, F_FRAG_K4 = 5, F_RESAMPLE = 6, F_VEC = 7, F_FRAG_BF3 = 8 };
     size_t add_untagged(size_t n) {
         size_t o = total;
         total += ((n + 3) / 4) * 4;  // keep every tensor 16-byte aligned
@@ -817,6 +878,20 @@ struct Packer {
     // Conv1d k5 weight (Cout, Cin, 5) [+ the block's residual 1x1 conv (Cout, Cin, 1)] -> the B-fragment stream of
     // wide_conv_kernel: [Cout/32][CinP/8][slots][64][4], slots = the taps that can be valid at length L (+ the residual)
     size_t conv_frag(const float* w, const float* wres, int cout, int cin, int cinp, int L) {
+        if (bf3_select(cout, L, WK_K5)) {  // bf3.hip: stream of bf16 triples [Cout/16][CinP/32][slots][3][64][8 bf16] (counted in floats here)
+            const int nslot = 5 + (wres ? 1 : 0);
+            tag(F_FRAG_BF3), tag(cout), tag(cinp), tag(L), tag(wres ? 1 : 0);
+            const size_t o = add(bf3_stream_elems(cout, cinp, nslot) / 2);
+            if (dry) return o;
+            std::vector<float> tmp((size_t)6 * cout * cinp, 0.0f);
+            for (int co = 0; co < cout; ++co)
+                for (int ci = 0; ci < cin; ++ci) {
+                    for (int t = 0; t < 5; ++t) tmp[((size_t)t * cout + co) * cinp + ci] = w[((size_t)co * cin + ci) * 5 + t];
+                    if (wres) tmp[((size_t)5 * cout + co) * cinp + ci] = wres[(size_t)co * cin + ci];
+                }
+            pack_fragments_bf3(tmp.data(), cout, cinp, 5, wres != nullptr, reinterpret_cast<unsigned short*>(&host[o]));
+            return o;
+        }
         const int sw = wide_ms(cout, L, WK_K5);
         const int kt0 = (L == 2) ? 1 : 0, ntap = (L == 2) ? 3 : 5, nslab = ntap + (wres ? 1 : 0);
         tag((L == 4 && sw == 32 && karatsuba_l4()) ? F_FRAG_K4 : (L == 2 && sw == 32 && cout / 8 == 64 && karatsuba_l2()) ? F_FRAG_K2 : F_FRAG);
@@ -843,6 +918,18 @@ struct Packer {
     }
     // strided Conv1d k3 (Cout, Cin, 3) or ConvTranspose1d k4 (Cin, Cout, 4) of a wide level -> fragment stream, slot = tap
     size_t resample_frag(const float* w, int cin, int cout, int k, bool transposed, int Lin) {
+        if (bf3_select(cout, Lin, transposed ? WK_UP : WK_DOWN)) {  // bf3.hip: bf16-triple stream, slot = tap
+            tag(F_FRAG_BF3), tag(F_RESAMPLE), tag(cout), tag(cin), tag(k), tag(transposed ? 1 : 0);
+            const size_t o = add(bf3_stream_elems(cout, cin, k) / 2);
+            if (dry) return o;
+            std::vector<float> tmp((size_t)6 * cout * cin, 0.0f);
+            for (int co = 0; co < cout; ++co)
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int t = 0; t < k; ++t)
+                        tmp[((size_t)t * cout + co) * cin + ci] = transposed ? w[((size_t)ci * cout + co) * k + t] : w[((size_t)co * cin + ci) * k + t];
+            pack_fragments_bf3(tmp.data(), cout, cin, k, false, reinterpret_cast<unsigned short*>(&host[o]));
+            return o;
+        }
         const int sw = wide_ms(cout, Lin, transposed ? WK_UP : WK_DOWN);
         tag(F_RESAMPLE), tag(cout), tag(cin), tag(k), tag(transposed ? 1 : 0), tag(sw);
         if (dry) return add((size_t)(cout / sw) * (cin / (sw == 32 ? 8 : 16)) * k * 256);
@@ -1402,12 +1489,18 @@ static void resolve_program(UNet* u, const LayerPlan& pl) {
             op.rc_L = o.Lin;
             op.wrs_kind = o.blk;
             op.rc_ms = wide_ms(o.Cout, o.Lin, o.blk);
+            op.rc_bf3 = bf3_select(o.Cout, o.Lin, o.blk) ? 1 : 0;
             op.flops_nominal = o.fn;
             op.flops_exec = o.fe;
             u->flops_nominal += o.fn;
             u->flops_exec += o.fe;
             op.flops_direct = o.fd > 0 ? o.fd : o.fe;
             u->flops_direct += op.flops_direct;
+            if (op.rc_bf3) {
+                op.flops_bf16 = 6.0 * op.flops_direct;
+                u->flops_bf16 += op.flops_bf16;
+                u->flops_f32_moved += op.flops_exec;
+            }
         } else if (o.kind == OP_RCB) {
             RcbP& c = op.rc;
             c.src1 = u->bufs[o.src1];
@@ -1427,6 +1520,7 @@ static void resolve_program(UNet* u, const LayerPlan& pl) {
             op.rc_L = o.Lin;
             op.rc_form = rcb_form(o.Cout, o.Lin);
             op.rc_ms = wide_ms(o.Cout, o.Lin, WK_K5);
+            op.rc_bf3 = (op.rc_form == 0 && bf3_select(o.Cout, o.Lin, WK_K5)) ? 1 : 0;
             op.tb_off = o.tb_off;
             op.flops_nominal = o.fn;
             op.flops_exec = o.fe;
@@ -1434,6 +1528,11 @@ static void resolve_program(UNet* u, const LayerPlan& pl) {
             u->flops_exec += o.fe;
             op.flops_direct = o.fd > 0 ? o.fd : o.fe;
             u->flops_direct += op.flops_direct;
+            if (op.rc_bf3) {  // six exact partial products per fp32 product, issued on the bf16 pipe
+                op.flops_bf16 = 6.0 * op.flops_direct;
+                u->flops_bf16 += op.flops_bf16;
+                u->flops_f32_moved += op.flops_exec;
+            }
         } else {
             GnP& g = op.gn;
             g.y = u->bufs[o.y];
@@ -1643,7 +1742,7 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
             p.src1 = coff(p.src1), p.src2 = coff(p.src2), p.dst = coff(p.dst), p.add_res = coff(p.add_res), p.res_out = coff(p.res_out);
             p.add_tb = op.tb_off >= 0 ? trow + op.tb_off : nullptr;
             EDMP_REQUIRE(!(p.add_tb && p.add_res), "fused conv block: a launch adds the time bias (conv1) or the residual (conv2), not both");
-            rc = launch_rcb(p, op.rc_L, op.rc_form, op.rc_ms, s);
+            rc = launch_rcb(p, op.rc_L, op.rc_form, op.rc_ms, op.rc_bf3, s);
         } else if (op.kind == OP_LVL && op.lv_merge) {
             const Op& nx = u->prog[op_index + 1];
             LevelP pa = op.lv, pb = nx.lv;
@@ -1669,7 +1768,7 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
             RcbP p = op.rc;
             p.B = B;
             p.src1 = coff(p.src1), p.dst = coff(p.dst);
-            rc = launch_wrs(p, op.wrs_kind, op.rc_L, op.rc_ms, s);
+            rc = launch_wrs(p, op.wrs_kind, op.rc_L, op.rc_ms, op.rc_bf3, s);
         } else if (op.kind == OP_CONV) {
             ConvP p = op.cv;
             p.B = B;
@@ -1780,6 +1879,22 @@ extern "C" int edmp_unet_flops(edmp_ctx* ctx, double* nominal, double* executed)
     EDMP_REQUIRE(ctx && ctx->unet, "no model loaded");
     if (nominal) *nominal = ctx->unet->flops_nominal;
     if (executed) *executed = ctx->unet->flops_exec;
+    return EDMP_OK;
+}
+
+extern "C" int edmp_unet_flops_pipes(edmp_ctx* ctx, double* f32_issued, double* bf16_issued) {
+    EDMP_REQUIRE(ctx && ctx->unet, "no model loaded");
+    if (f32_issued) *f32_issued = ctx->unet->flops_exec - ctx->unet->flops_f32_moved;
+    if (bf16_issued) *bf16_issued = ctx->unet->flops_bf16;
+    return EDMP_OK;
+}
+
+extern "C" int edmp_prof_ops_bf16(edmp_ctx* ctx, int cap, int* n_ops, double* flops_bf16) {
+    EDMP_REQUIRE(ctx && ctx->unet && n_ops, "edmp_prof_ops_bf16: null argument / no model");
+    const int n = (int)ctx->unet->prog.size();
+    *n_ops = n;
+    for (int i = 0; i < n && i < cap; ++i)
+        if (flops_bf16) flops_bf16[i] = ctx->unet->prog[i].flops_bf16;
     return EDMP_OK;
 }
 

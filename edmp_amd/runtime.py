@@ -190,6 +190,14 @@ class Context:
             out.append((nm, int(calls[i]), float(ms[i]), float(fl[i])))
         return out
 
+    def prof_ops_bf16(self):
+        """per program op: FLOPs per trajectory per launch issued on the bf16 matrix pipe (bf16x3 ops; 0 for fp32-MFMA ops)."""
+        cap = 256
+        n = C.c_int()
+        fl = (C.c_double * cap)()
+        _capi.check(self.lib.edmp_prof_ops_bf16(self.h, cap, C.byref(n), fl))
+        return [float(fl[i]) for i in range(min(n.value, cap))]
+
 
 _slot_counter = [0]
 

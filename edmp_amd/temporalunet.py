@@ -160,6 +160,13 @@ class TemporalUNet:
         _capi.check(self.ctx.lib.edmp_unet_flops(self.ctx.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def flops_by_pipe(self):
+        """(fp32-pipe, bf16-pipe) MFMA FLOPs issued per trajectory per forward (see edmp_unet_flops_pipes)."""
+        self._bind()
+        a, b = C.c_double(), C.c_double()
+        _capi.check(self.ctx.lib.edmp_unet_flops_pipes(self.ctx.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def pack(self, path=None):
         """Write the device weight image next to the checkpoint (<model_name>/weights_packed.edmp, or ``path``): later
         constructions of this architecture load it with one mmap + one copy.  No reference counterpart."""

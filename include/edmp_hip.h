@@ -84,6 +84,10 @@ int edmp_unet_flops(edmp_ctx* ctx, double* nominal, double* executed);
  * "executed" figure, 122.0 MFLOP for the full-size net).  edmp_unet_flops' `executed` counts the MFMA work actually
  * issued, which is lower where the L = 2 / L = 4 convolutions run in Karatsuba form (wide.hip). */
 int edmp_unet_flops_direct(edmp_ctx* ctx, double* direct);
+/* Where the issued MFMA work of one forward runs (no reference counterpart; bench.py's roofline): FLOPs per trajectory issued on
+ * the fp32 matrix pipe (edmp_unet_flops' `executed` minus the work of the layers that run in bf16x3 form) and on the bf16 matrix
+ * pipe (csrc/bf3.hip: six exact bf16 partial products per fp32 product, fp32 accumulation; 0 with EDMP_BF16X3=0). */
+int edmp_unet_flops_pipes(edmp_ctx* ctx, double* f32_issued, double* bf16_issued);
 
 /* ---- guide: IntersectionVolumeGuide -------------------------------------------------------------------- */
 /* replaces IntersectionVolumeGuide.__init__/define_link_information/define_obstacles
@@ -243,6 +247,8 @@ int edmp_prof_read(edmp_ctx* ctx, double* conv_ms, int64_t* conv_launches, int r
  * op i < min(*n_ops, cap) of the loaded UNet's layer program: summed event time [ms], launches, executed FLOPs per
  * trajectory per launch, and the kernel instance name (64 bytes each, as rocprofv3 prints it without "edmp::"). */
 int edmp_prof_ops(edmp_ctx* ctx, int cap, int* n_ops, double* ms, int64_t* calls, double* flops_exec, char* names);
+/* per op of the same program: FLOPs per trajectory per launch issued on the bf16 matrix pipe (0 for an fp32-MFMA op) */
+int edmp_prof_ops_bf16(edmp_ctx* ctx, int cap, int* n_ops, double* flops_bf16);
 
 #ifdef __cplusplus
 }

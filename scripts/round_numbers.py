@@ -49,7 +49,7 @@ if c:
     print(f"* cpu_baseline ({c['kind']}): {c['value']:.0f} {c['unit']} on {c['cores']} cores; {c['sample']}")
 print("\n| kernel | launches | avg us | share | TFLOP/s issued | frac |\n|---|---:|---:|---:|---:|---:|")
 for r in rf["per_kernel"]:
-    print(f"| `{r['kernel']}` | {r['launches']} | {r['avg_us']:.2f} | {r['share']:.3f} | {r['executed_tflops']:.1f} | {r['frac']:.3f} |")
+    print(f"| `{r['kernel']}` | {r['launches']} | {r['avg_us']:.2f} | {r['share']:.3f} | {r.get('executed_tflops', r.get('issued_tflops', 0.0)):.1f}{' (bf16 pipe)' if r.get('pipe') == 'bf16' else ''} | {r['frac']:.3f} |")
 lv = [r for r in rf["per_kernel"] if r["kernel"].startswith(("level_kernel", "level2_kernel"))]
 print(f"\nLevel kernels per reverse step: {sum(r['avg_us'] for r in lv):.1f} us in {len(lv)} launches.")
 
