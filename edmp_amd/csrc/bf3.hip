@@ -60,8 +60,12 @@ struct Bf3Cfg {
     static constexpr int NTH = 512, NMW = 4;  // threads; MFMA waves (waves 4..7 stage)
     static constexpr int LOUT = (KIND == WK_K5) ? LIN : (KIND == WK_DOWN) ? (LIN - 1) / 2 + 1 : ((2 * LIN == 8 || 2 * LIN == 14 || 2 * LIN == 26) ? 2 * LIN - 1 : 2 * LIN);
     static constexpr bool GN = (KIND == WK_K5);
-    static constexpr int SW = 16, S = CG / SW, PARTS = NMW / S;
-    static constexpr bool ROWSPLIT = (MS == 32);  // the two waves of a slab: sample halves (MS = 32) | output-position sets (MS = 16)
+    static constexpr int SW = 16, S = CG / SW, PARTS = NMW / S;  // CG = 32: two slabs x two parts; CG = 64: four slabs, one wave each
+    static constexpr bool ROWSPLIT = (PARTS == 2 && MS == 32);  // the two waves of a slab: sample halves (MS = 32) | output-position sets (MS = 16)
+    static constexpr int NR = (PARTS == 1) ? MS / 16 : 1;       // 16-sample row blocks per wave (CG = 64: both halves of the 32 samples, sharing every weight fragment)
+    // the residual tiles in ONE accumulator where two would not fit the 256 registers (L = 13 with the folded residual conv: 26 tiles; the
+    // residual 1x1 conv has K = Cin only, so its 6 roundings per 32-term dot product stay below the fp32-MFMA kernel's 8)
+    static constexpr bool RES_ONE_ACC = RES && MS == 16 && LIN >= 13;
     static constexpr int KC = 32;                 // channels per chunk = K of v_mfma_f32_16x16x32_bf16
     static constexpr int RS = KC + 8;             // bf16 per staged row (80 B: the 16 rows of a ds_read_b128 phase hit all 64 banks once)
     static constexpr int PLANE = MS * RS;
@@ -88,7 +92,7 @@ struct Bf3Cfg {
     }
     // position-set split: the subset of output positions for part 0 whose pair count is closest to half (ties: fewer tiles)
     static constexpr unsigned part0_mask() {
-        if (ROWSPLIT) return ~0u;
+        if (ROWSPLIT || PARTS == 1) return ~0u;
         const int tot = total_pairs();
         int pc[16] = {};
         for (int l = 0; l < LOUT; ++l) pc[l] = pairs_of(l);
@@ -104,7 +108,7 @@ struct Bf3Cfg {
     }
     static constexpr unsigned P0 = part0_mask();
     static constexpr bool owned(int tile, int H) {
-        if (ROWSPLIT) return true;
+        if (ROWSPLIT || PARTS == 1) return true;
         const int l = tile < LOUT ? tile : tile - LOUT;
         return (int)((P0 >> l) & 1u) == (H == 0 ? 1 : 0);
     }
@@ -144,7 +148,7 @@ struct Bf3Cfg {
         const size_t a = 2 * (size_t)STAGE * 2, y = (size_t)MS * (YS + (RES ? RYS : 0)) * 4;
         return a > y ? a : y;
     }
-    static_assert(CG == 32 && S == 2 && PARTS == 2, "two 16-channel slabs x two parts = the four MFMA waves");
+    static_assert((CG == 32 && S == 2 && PARTS == 2) || (CG == 64 && S == 4 && PARTS == 1 && MS == 32), "two 16-channel slabs x two parts, or four slabs = the four MFMA waves");
     static_assert(MS == 32 || MS == 16, "32 samples (sample-half parts) or 16 samples (position-set parts)");
     static_assert(!RES || KIND == WK_K5, "the folded residual 1x1 conv belongs to a Conv1dBlock");
     static_assert(!GN || CG % GS == 0, "whole GroupNorm groups per workgroup");
@@ -173,7 +177,8 @@ __global__ __launch_bounds__(512) void bf3_conv_kernel(const float* a_src1, cons
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool mfma_wave = wave < 4;
-    const int s = wave & 1, part = (wave >> 1) & 1;
+    const int s = wave & (Cf::S - 1), part = (Cf::PARTS == 2) ? (wave >> 1) & 1 : 0;
+    constexpr int NR = Cf::NR;
     int grp, tile;
     {
         const int lin = blockIdx.x;
@@ -190,6 +195,14 @@ __global__ __launch_bounds__(512) void bf3_conv_kernel(const float* a_src1, cons
     const int co0 = grp * CG, b0 = tile * MS;
     const int ch1 = a_C1 / KC, ch2 = a_C2 / KC, nK = ch1 + ch2;
     EDMP_BF3_STAMP(0)
+    // The workgroup claims its waves' WHOLE register budget (2 waves per SIMD x 256 VGPRs = the SIMD's file): no wave of another kernel
+    // can share a CU with it.  Measured need, not tidiness: with the 124-244 registers the kernels actually use, waves of the guide's
+    // gradient kernel (guide.hip: guide_kernel<GM_GRAD>) that landed on a CU beside a bf16x3 workgroup - row chains, two scenes in
+    // flight: other streams - came back with lanes 48-63 of ONE register changed in ~0.1 % of the launches (one gradient element of one
+    // row; never with the fp32-MFMA program, never with this line: profiles/r06_coresidency_fault.md).  Cause not found (no LDS
+    // overrun: padding the allocation changes nothing; no register beyond the declared count in the ISA; a pure-VALU canary kernel
+    // beside the same launches stays bit-exact); the single-stream path never shares a CU anyway (one workgroup per CU).
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");
 
     // ---- staging side (waves 4..7): item e = (position, sample row, channel quad) of a chunk
     const int ptid = tid & 255;
@@ -238,14 +251,17 @@ __global__ __launch_bounds__(512) void bf3_conv_kernel(const float* a_src1, cons
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) bw[m][j] = *reinterpret_cast<const u32x4_t*>(w + j * 3 * 1024);
     };
-    f32x4_t big[MAXT], sml[MAXT];
+    f32x4_t big[MAXT][NR], sml[MAXT][NR];
 #pragma unroll
-    for (int a = 0; a < MAXT; ++a) {
-        big[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        sml[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    }
-    // A fragment of a lane: sample row lane % 16 of the wave's rows, channel octet lane / 16
+    for (int a = 0; a < MAXT; ++a)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            big[a][r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            sml[a][r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+    // A fragment of a lane: sample row lane % 16 of the wave's row block(s), channel octet lane / 16 (row block r: + 16 r rows)
     const int afrag = ((Cf::ROWSPLIT ? 16 * part : 0) + (lane & 15)) * RS + 8 * (lane >> 4);
+    constexpr int RBLK = 16 * RS;
 
     // one chunk of part H on stage `st` in two PHASES: A = the weight components lo and mid, B = the weight component hi (87 of the
     // 174 MFMAs each at L = 7); inside a phase one entry per needed input position: its activation components against every tile
@@ -256,11 +272,14 @@ __global__ __launch_bounds__(512) void bf3_conv_kernel(const float* a_src1, cons
     // is requested half a chunk (~1.4 k cycles) before its first use.
     auto chunk = [&](auto hc, const unsigned short* st, int kgn) __attribute__((always_inline)) {
         constexpr int H = decltype(hc)::value;
-        u32x4_t av[2][3];
+        u32x4_t av[2][NR][3];
         {   // first entry (phase A: components hi, mid)
             constexpr int lp0 = Cf::first(H) % LIN;
-            av[0][0] = *reinterpret_cast<const u32x4_t*>(st + (lp0 * 3 + 0) * PLANE + afrag);
-            av[0][1] = *reinterpret_cast<const u32x4_t*>(st + (lp0 * 3 + 1) * PLANE + afrag);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                av[0][r][0] = *reinterpret_cast<const u32x4_t*>(st + (lp0 * 3 + 0) * PLANE + r * RBLK + afrag);
+                av[0][r][1] = *reinterpret_cast<const u32x4_t*>(st + (lp0 * 3 + 1) * PLANE + r * RBLK + afrag);
+            }
         }
         static_for<0, 2>([&](auto pc) __attribute__((always_inline)) {
             constexpr int ph = decltype(pc)::value;
@@ -273,7 +292,9 @@ __global__ __launch_bounds__(512) void bf3_conv_kernel(const float* a_src1, cons
                     if constexpr (qn >= 0) {  // next entry's fragments: phase A reads the components hi and mid, phase B all three
                         constexpr int lpn = qn % LIN, ncomp = (qn / LIN == 0) ? 2 : 3;
 #pragma unroll
-                        for (int m = 0; m < ncomp; ++m) av[buf ^ 1][m] = *reinterpret_cast<const u32x4_t*>(st + (lpn * 3 + m) * PLANE + afrag);
+                        for (int r = 0; r < NR; ++r)
+#pragma unroll
+                            for (int m = 0; m < ncomp; ++m) av[buf ^ 1][r][m] = *reinterpret_cast<const u32x4_t*>(st + (lpn * 3 + m) * PLANE + r * RBLK + afrag);
                     }
                     // products (activation component ia, weight component wc), kept iff ia + wc <= 2; phase A: (hi, lo) (mid, mid) (hi, mid); phase B: (lo, hi) (mid, hi) (hi, hi)
                     static_for<0, 3>([&](auto kc) __attribute__((always_inline)) {
@@ -285,10 +306,14 @@ __global__ __launch_bounds__(512) void bf3_conv_kernel(const float* a_src1, cons
                             if constexpr (Cf::owned(tl, H) && Cf::tslot(tl, lp) >= 0) {
                                 constexpr int sl = Cf::tslot(tl, lp) >= 0 ? Cf::tslot(tl, lp) : 0;
                                 constexpr int la = Cf::local(tl, H);
-                                if constexpr (ia == 0 && wc == 0)
-                                    big[la] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[buf][0]), __builtin_bit_cast(bf16x8_t, bw[0][sl]), big[la], 0, 0, 0);
-                                else
-                                    sml[la] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[buf][ia]), __builtin_bit_cast(bf16x8_t, bw[wc][sl]), sml[la], 0, 0, 0);
+                                constexpr bool one_acc = Cf::RES_ONE_ACC && tl >= LOUT;
+#pragma unroll
+                                for (int r = 0; r < NR; ++r) {  // (the row blocks share the weight fragment)
+                                    if constexpr ((ia == 0 && wc == 0) || one_acc)
+                                        big[la][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[buf][r][ia]), __builtin_bit_cast(bf16x8_t, bw[wc][sl]), big[la][r], 0, 0, 0);
+                                    else
+                                        sml[la][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[buf][r][ia]), __builtin_bit_cast(bf16x8_t, bw[wc][sl]), sml[la][r], 0, 0, 0);
+                                }
                             }
                         });
                     });
@@ -329,7 +354,7 @@ __global__ __launch_bounds__(512) void bf3_conv_kernel(const float* a_src1, cons
         }
     };
     if (mfma_wave) {
-        if (Cf::ROWSPLIT || part == 0) mfma_loop(std::integral_constant<int, 0>{});
+        if (Cf::ROWSPLIT || Cf::PARTS == 1 || part == 0) mfma_loop(std::integral_constant<int, 0>{});
         else mfma_loop(std::integral_constant<int, 1>{});
     } else {
         // step c: split + commit chunk c + 1 (fetched a step ago or in the prologue) into the other stage, fetch chunk c + 3 into its registers
@@ -379,18 +404,21 @@ __global__ __launch_bounds__(512) void bf3_conv_kernel(const float* a_src1, cons
             constexpr int tl = decltype(tc)::value;
             if constexpr (Cf::owned(tl, H)) {
                 constexpr int la = Cf::local(tl, H);
-                if constexpr (tl < LOUT) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Y[(row0 + r) * YS + tl * CG + col] = (big[la][r] + sml[la][r]) + bias_v;
-                } else {
+                for (int rb = 0; rb < NR; ++rb) {
+                    if constexpr (tl < LOUT) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) R[(row0 + r) * RYS + (tl - LOUT) * CG + col] = (big[la][r] + sml[la][r]) + rbias_v;
+                        for (int r = 0; r < 4; ++r) Y[(row0 + 16 * rb + r) * YS + tl * CG + col] = (big[la][rb][r] + sml[la][rb][r]) + bias_v;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) R[(row0 + 16 * rb + r) * RYS + (tl - LOUT) * CG + col] = (big[la][rb][r] + sml[la][rb][r]) + rbias_v;
+                    }
                 }
             }
         });
     };
     if (mfma_wave) {
-        if (Cf::ROWSPLIT || part == 0) spill(std::integral_constant<int, 0>{});
+        if (Cf::ROWSPLIT || Cf::PARTS == 1 || part == 0) spill(std::integral_constant<int, 0>{});
         else spill(std::integral_constant<int, 1>{});
     }
     __syncthreads();

@@ -511,8 +511,12 @@ __global__ void argmin_kernel(const float* __restrict__ v, int n, int* __restric
     if (lane == 0) out[0] = (bi == 0x7fffffff) ? 0 : bi;
 }
 
-static int ensure_scratch(edmp_ctx* ctx, Guide* g, int B, int L) {
+// *realloc (optional) is set when the blocks were replaced: captured graphs baked the old pointers in (the pool can hand
+// the SAME graw block back while rowsq / vol_rows move, so comparing one pointer is not enough)
+static int ensure_scratch(edmp_ctx* ctx, Guide* g, int B, int L, bool* realloc = nullptr) {
+    if (realloc) *realloc = false;
     if (g->scratch_B >= B && g->scratch_L >= L) return EDMP_OK;
+    if (realloc) *realloc = true;
     for (void* p : {(void*)g->graw, (void*)g->rowsq, (void*)g->vol_rows}) ctx_release(ctx, p);
     g->graw = nullptr;
     g->rowsq = nullptr;
@@ -564,9 +568,7 @@ static int launch_guide(edmp_ctx* ctx, const TIn* joints, int ldw, int off, int 
     a.row0 = row0;
     hipStream_t st = run_stream ? run_stream : ctx->stream;
     if constexpr (MODE == GM_GRAD) {
-        // EDMP_GUIDE_SPLIT=1: the one-wave-per-row layout for the gradient too (A/B runs)
-        static const bool split = [] { const char* e = getenv("EDMP_GUIDE_SPLIT"); return !(e && e[0] == '1'); }();
-        if (split) {
+        if (g->split4) {  // (EDMP_GUIDE_SPLIT, read when the guide object was created)
             hipLaunchKernelGGL((guide_kernel<MODE, TIn, 4>), dim3(n - row0), dim3(256), 0, st, a, g->rc);
             EDMP_HIP_CHECK(hipGetLastError());
             return EDMP_OK;
@@ -581,9 +583,9 @@ static int launch_guide(edmp_ctx* ctx, const TIn* joints, int ldw, int off, int 
 int guide_prepare(edmp_ctx* ctx, int B, int L) {  // allocate the step scratch up front (nothing may allocate inside a graph capture)
     Guide* g = ctx->guide;
     EDMP_REQUIRE(g, "scene/rows not set");
-    const float* before = g->graw;
-    int rc = ensure_scratch(ctx, g, B, L);
-    if (g->graw != before) ctx->epoch++;
+    bool moved = false;
+    int rc = ensure_scratch(ctx, g, B, L, &moved);
+    if (moved) ctx->epoch++;
     return rc;
 }
 // reduce = false: the caller's update kernel sums the per-row partials itself (device-resident loop without a hook)
@@ -653,11 +655,17 @@ extern "C" int edmp_scene_set(edmp_ctx* ctx, const double* obstacle_config, int 
     // null-stream copy - a scene change on one context must not wait for another context's queued loop, see common.h)
     if (!ctx->guide) {
         ctx->guide = new Guide();
+        {   // EDMP_GUIDE_SPLIT=1: the one-wave-per-row layout for the gradient too (A/B runs); frozen into the object like the model builder's switches
+            const char* e = getenv("EDMP_GUIDE_SPLIT");
+            ctx->guide->split4 = !(e && e[0] == '1');
+        }
         if (int rc = ctx_alloc(ctx, (void**)&ctx->guide->sumsq, sizeof(double))) return rc;
         if (int rc = ctx_alloc(ctx, (void**)&ctx->guide->startgoal, 14 * sizeof(float))) return rc;
         EDMP_HIP_CHECK(hipMemsetAsync(ctx->guide->startgoal, 0, 14 * sizeof(float), ctx->stream));
     }
     Guide* g = ctx->guide;
+    // nothing enqueued may still read the tables that go back to the pool (as edmp_rows_set; hipFree used to wait for every stream)
+    EDMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (void** p : {(void**)&g->aabb, (void**)&g->obb, (void**)&g->kind}) {
         ctx_release(ctx, *p);
         *p = nullptr;
@@ -692,21 +700,22 @@ extern "C" int edmp_scene_set(edmp_ctx* ctx, const double* obstacle_config, int 
             obb[o * 16 + 12 + k] = c[7 + k] / 2;  // the simulator's half extents (lib/environment.py:235)
         }
     }
-    if (int rc = ctx_alloc(ctx, (void**)&g->obb, obb.size() * sizeof(double))) return rc;
-    if (int rc = ctx_alloc(ctx, (void**)&g->kind, no * sizeof(int32_t))) return rc;
+    // every block first, then every enqueued copy, then ONE synchronise that all exits pass through: the host vectors and the caller's
+    // arrays are read by the enqueued copies (an early return used to leave a copy from a local vector in flight)
     hipStream_t st = ctx->stream;
-    EDMP_HIP_CHECK(hipMemcpyAsync(g->obb, obb.data(), obb.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    EDMP_HIP_CHECK(hipMemsetAsync(g->kind, 0, no * sizeof(int32_t), st));  // every obstacle a cuboid until edmp_scene_set_shapes says otherwise
-    // one staging block for the table kernel's inputs: sizes | clearance | expansion (f64), then the transforms (f32)
     const size_t n_sz = sizes.size(), n_gt = (size_t)G * T;
-    double* d_in = nullptr;
-    if (int rc = ctx_alloc(ctx, (void**)&d_in, (n_sz + 2 * n_gt) * sizeof(double) + tf.size() * sizeof(float))) return rc;
-    double *d_sizes = d_in, *d_clr = d_in + n_sz, *d_exp = d_clr + n_gt;
-    float* d_tf = reinterpret_cast<float*>(d_exp + n_gt);
-    int rc = ctx_alloc(ctx, (void**)&g->aabb, (size_t)G * (T + 1) * no * 6 * sizeof(float));
+    double* d_in = nullptr;  // one staging block for the table kernel's inputs: sizes | clearance | expansion (f64), then the transforms (f32)
+    int rc = ctx_alloc(ctx, (void**)&g->obb, obb.size() * sizeof(double));
+    if (!rc) rc = ctx_alloc(ctx, (void**)&g->kind, no * sizeof(int32_t));
+    if (!rc) rc = ctx_alloc(ctx, (void**)&d_in, (n_sz + 2 * n_gt) * sizeof(double) + tf.size() * sizeof(float));
+    if (!rc) rc = ctx_alloc(ctx, (void**)&g->aabb, (size_t)G * (T + 1) * no * 6 * sizeof(float));
     hipError_t e = hipSuccess;
     if (!rc) {
-        e = hipMemcpyAsync(d_sizes, sizes.data(), n_sz * sizeof(double), hipMemcpyHostToDevice, st);
+        double *d_sizes = d_in, *d_clr = d_in + n_sz, *d_exp = d_clr + n_gt;
+        float* d_tf = reinterpret_cast<float*>(d_exp + n_gt);
+        e = hipMemcpyAsync(g->obb, obb.data(), obb.size() * sizeof(double), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemsetAsync(g->kind, 0, no * sizeof(int32_t), st);  // every obstacle a cuboid until edmp_scene_set_shapes says otherwise
+        if (e == hipSuccess) e = hipMemcpyAsync(d_sizes, sizes.data(), n_sz * sizeof(double), hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(d_tf, tf.data(), tf.size() * sizeof(float), hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(d_clr, clearance, n_gt * sizeof(double), hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(d_exp, expansion, n_gt * sizeof(double), hipMemcpyHostToDevice, st);
@@ -715,7 +724,6 @@ extern "C" int edmp_scene_set(edmp_ctx* ctx, const double* obstacle_config, int 
             hipLaunchKernelGGL(obstacle_table_kernel, dim3((total + 255) / 256), dim3(256), 0, st, d_sizes, d_tf, d_clr, d_exp, g->aabb, G, T, no);
             e = hipGetLastError();
         }
-        // the host vectors and the caller's arrays are read by the enqueued copies: complete them before returning
         const hipError_t e2 = hipStreamSynchronize(st);
         if (e == hipSuccess) e = e2;
     }
@@ -853,3 +861,4 @@ extern "C" int edmp_row_swept_volumes_dev(edmp_ctx* ctx, const double* X_dev, in
     }
     return EDMP_OK;
 }
+

@@ -51,7 +51,11 @@
     X(18, WK_DOWN, 32, 32, 32, 4, false) \
     X(16, WK_UP, 32, 32, 32, 2, false)   \
     X(17, WK_DOWN, 16, 32, 16, 13, false) \
-    X(18, WK_UP, 16, 32, 16, 7, false)
+    X(18, WK_UP, 16, 32, 16, 7, false)    \
+    X(19, WK_K5, 32, 64, 64, 4, true)     \
+    X(20, WK_K5, 32, 64, 64, 4, false)    \
+    X(19, WK_K5, 32, 32, 32, 4, true)     \
+    X(20, WK_K5, 32, 32, 32, 4, false)
 
 // X(shard, MODE, C, L, SB, CIN)
 #define EDMP_LEVEL_INSTANCES(X)        \
@@ -69,4 +73,4 @@
     X(14, LV_DOWN, 32, 50, 8, LV_DOWN, 64, 25, 32, 2) \
     X(15, LV_UP, 64, 13, 256, LV_UP_FINAL, 32, 25, 128, 2)
 
-#define EDMP_KERNEL_SHARDS 19
+#define EDMP_KERNEL_SHARDS 21

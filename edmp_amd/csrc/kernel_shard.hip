@@ -38,6 +38,8 @@ namespace edmp {
 #define EDMP_SHARD_16(...)
 #define EDMP_SHARD_17(...)
 #define EDMP_SHARD_18(...)
+#define EDMP_SHARD_19(...)
+#define EDMP_SHARD_20(...)
 #if EDMP_SHARD == 0
 #undef EDMP_SHARD_0
 #define EDMP_SHARD_0(...) __VA_ARGS__
@@ -95,6 +97,12 @@ namespace edmp {
 #elif EDMP_SHARD == 18
 #undef EDMP_SHARD_18
 #define EDMP_SHARD_18(...) __VA_ARGS__
+#elif EDMP_SHARD == 19
+#undef EDMP_SHARD_19
+#define EDMP_SHARD_19(...) __VA_ARGS__
+#elif EDMP_SHARD == 20
+#undef EDMP_SHARD_20
+#define EDMP_SHARD_20(...) __VA_ARGS__
 #else
 #error "EDMP_SHARD out of range"
 #endif

@@ -573,9 +573,44 @@ static bool rcb_supported(int cout, int L, int c1, int c2) {
     const bool shape = (cg == 64 && (L == 2 || L == 4)) || (cg == 32 && (L == 4 || L == 7)) || (cg == 16 && (L == 7 || L == 13));
     return shape && cout % 8 == 0 && c1 % 32 == 0 && c2 % 32 == 0 && (c2 == 0 || c2 == c1);  // wide.hip: equal halves of a concat
 }
+// bf16x3 split (bf3.hip): the direct-form instances whose weights meet >= 7 positions run on the bf16 matrix pipe with exact
+// products and fp32 accumulation - measured x1.2-1.55 per launch at HALF the fp32-MFMA kernel's error against float64
+// (profiles/r06_bf16x3.md).  EDMP_BF16X3=<mask> (read at model-build time, frozen into the layer program and the packed image's
+// layout id): bit 0 Conv1dBlock L = 7 / 256 ch, bit 1 Conv1dBlock L = 7 / 128 ch, bit 2 Conv1dBlock L = 13 / 128 ch,
+// bit 3 the k3s2 (L = 7) / ConvTranspose (L = 4) resamplers at 256 channels, bit 4 those at 512 channels (L = 4 / L = 2), bit 5 those at
+// 128 channels (L = 13 / L = 7), bit 6 Conv1dBlock L = 4 / 512 ch, bit 7 Conv1dBlock L = 4 / 256 ch (direct form on the bf16 pipe instead of the
+// nested Karatsuba form on the fp32 pipe).  0 = every conv on the fp32-MFMA kernels (bench.py's A/B leg).
+static const int kBf3Default = 0xff;  // same-box bench A/Bs (profiles/r06_bf16x3.md): 0 -> 1 001 k, 0x7 -> 1 083 k, 0x3f -> 1 102 k traj-steps/s; another box: 0x3f 1 067 k, 0x7f 1 101 k, 0xbf 1 087 k, 0xff -> 1 120 k
+static int bf3_mask() {
+    const char* e = getenv("EDMP_BF16X3");
+    return e ? (int)strtol(e, nullptr, 0) : kBf3Default;
+}
+// kind: WK_K5 (a Conv1dBlock; L = its length), WK_DOWN / WK_UP (L = input length)
+static bool bf3_select(int cout, int L, int kind) {
+    const int cg = cout / 8, m = bf3_mask();
+    if (kind == WK_K5) {
+        if (cg == 32 && L == 7) return m & 1;
+        if (cg == 16 && L == 7) return m & 2;
+        if (cg == 16 && L == 13) return m & 4;
+        if (cg == 64 && L == 4) return m & 64;
+        if (cg == 32 && L == 4) return m & 128;
+    }
+    if (kind == WK_DOWN) {
+        if (cg == 32 && L == 7) return m & 8;
+        if (cg == 64 && L == 4) return m & 16;
+        if (cg == 16 && L == 13) return m & 32;
+    }
+    if (kind == WK_UP) {
+        if (cg == 32 && L == 4) return m & 8;
+        if (cg == 64 && L == 2) return m & 16;
+        if (cg == 16 && L == 7) return m & 32;
+    }
+    return false;
+}
 // form: 0 direct | 2 Karatsuba at L = 2 | 4 nested Karatsuba at L = 4 (rcb_form, frozen into the op at build time)
 static int rcb_form(int cout, int L) {
     const int cg = cout / 8;
+    if (bf3_select(cout, L, WK_K5)) return 0;  // bf3.hip runs the direct form
     if (cg == 64 && L == 2 && karatsuba_l2()) return 2;
     if (cg >= 32 && L == 4 && karatsuba_l4()) return 4;
     return 0;
@@ -593,37 +628,6 @@ static const int kMs16Default = 0x05;  // same-box bench A/B, three alternated r
 static int ms16_mask() {
     const char* e = getenv("EDMP_MS16");
     return e ? (int)strtol(e, nullptr, 0) : kMs16Default;
-}
-// bf16x3 split (bf3.hip): the direct-form instances whose weights meet >= 7 positions run on the bf16 matrix pipe with exact
-// products and fp32 accumulation - measured x1.2-1.55 per launch at HALF the fp32-MFMA kernel's error against float64
-// (profiles/r06_bf16x3.md).  EDMP_BF16X3=<mask> (read at model-build time, frozen into the layer program and the packed image's
-// layout id): bit 0 Conv1dBlock L = 7 / 256 ch, bit 1 Conv1dBlock L = 7 / 128 ch, bit 2 Conv1dBlock L = 13 / 128 ch,
-// bit 3 the k3s2 (L = 7) / ConvTranspose (L = 4) resamplers at 256 channels, bit 4 those at 512 channels (L = 4 / L = 2), bit 5 those at
-// 128 channels (L = 13 / L = 7).  0 = every conv on the fp32-MFMA kernels (bench.py's A/B leg).
-static const int kBf3Default = 0x3f;  // same-box bench A/B (profiles/r06_bf16x3.md): 0 -> 1 001 k, 0x7 -> 1 083 k, 0xf 1 091 k, 0x17 1 097 k, 0x27 1 086 k, 0x3f -> 1 102 k traj-steps/s
-static int bf3_mask() {
-    const char* e = getenv("EDMP_BF16X3");
-    return e ? (int)strtol(e, nullptr, 0) : kBf3Default;
-}
-// kind: WK_K5 (a Conv1dBlock; L = its length), WK_DOWN / WK_UP (L = input length)
-static bool bf3_select(int cout, int L, int kind) {
-    const int cg = cout / 8, m = bf3_mask();
-    if (kind == WK_K5) {
-        if (cg == 32 && L == 7) return m & 1;
-        if (cg == 16 && L == 7) return m & 2;
-        if (cg == 16 && L == 13) return m & 4;
-    }
-    if (kind == WK_DOWN) {
-        if (cg == 32 && L == 7) return m & 8;
-        if (cg == 64 && L == 4) return m & 16;
-        if (cg == 16 && L == 13) return m & 32;
-    }
-    if (kind == WK_UP) {
-        if (cg == 32 && L == 4) return m & 8;
-        if (cg == 64 && L == 2) return m & 16;
-        if (cg == 16 && L == 7) return m & 32;
-    }
-    return false;
 }
 // kind: WK_K5 (a Conv1dBlock; L = its length), WK_DOWN / WK_UP (L = input length)
 static int wide_ms(int cout, int L, int kind) {
@@ -648,7 +652,9 @@ static int launch_rcb(const RcbP& p, int L, int form, int ms, int bf3, hipStream
         if (cg == 32 && L == 7) { EDMP_B3(32, 32, 7) }
         if (cg == 16 && L == 7) { EDMP_B3(16, 16, 7) }
         if (cg == 16 && L == 13) { EDMP_B3(16, 16, 13) }
+        if (cg == 32 && L == 4) { EDMP_B3(32, 32, 4) }
 #undef EDMP_B3
+        if (cg == 64 && L == 4) return res ? launch_bf3_t<WK_K5, 32, 64, 64, 4, true>(p, s) : launch_bf3_t<WK_K5, 32, 64, 64, 4, false>(p, s);
         set_error("no bf16x3 conv+GroupNorm kernel for Cout=%d L=%d", p.Cout, L);
         return EDMP_ERR_STATE;
     }
@@ -1158,8 +1164,8 @@ struct LayerPlan {
             o.dst = pool.get();
             o.fn = 2.0 * a.L * cout * (double)cin_true * 5;
             // executed = issued MFMA work: the L = 2 Karatsuba form runs 3 matrix products where the direct form runs 4
-            const bool k2 = a.L == 2 && cout / 8 == 64 && karatsuba_l2() && rcb_supported(cout, a.L, o.C1, o.C2);
-            const bool k4 = a.L == 4 && cout / 8 >= 32 && karatsuba_l4() && rcb_supported(cout, a.L, o.C1, o.C2);
+            const bool k2 = a.L == 2 && rcb_form(cout, a.L) == 2 && rcb_supported(cout, a.L, o.C1, o.C2);
+            const bool k4 = a.L == 4 && rcb_form(cout, a.L) == 4 && rcb_supported(cout, a.L, o.C1, o.C2);
             o.fe = 2.0 * (k2 ? 3.0 : k4 ? 9.0 : (double)valid_pairs(a.L, a.L, 5, 1, 2, false)) * cout * (double)(o.C1 + o.C2);
             o.fd = 2.0 * (double)valid_pairs(a.L, a.L, 5, 1, 2, false) * cout * (double)(o.C1 + o.C2);
             pops.push_back(o);

@@ -38,6 +38,32 @@ using namespace edmp;
 #ifndef FCG  // output channels per workgroup of the fp32 instance (64 at 512 channels)
 #define FCG 32
 #endif
+#ifndef BCG  // ... of the bf16x3 instance (64 for a Conv1dBlock at 512 channels: whole GroupNorm groups)
+#define BCG 32
+#endif
+#ifndef FKIND  // kernel form of the fp32 instance (4 = WK_K5K4: the Conv1dBlock at L = 4 in nested Karatsuba form)
+#define FKIND KINDV
+#endif
+
+// canary: pure VALU work per lane (a long dependent fma / sin chain in f32 with a little f64), one result per thread: any deviation from a
+// solo run while another kernel shares the CUs is a co-residency fault, not a data race (the canary touches nothing but its own output)
+__global__ __launch_bounds__(256) void canary_kernel(float* out, int iters, float seed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float a = seed + 1e-3f * (float)(i & 1023), b = 0.5f, g[7] = {0, 0, 0, 0, 0, 0, 0};
+    double d = 1.0;
+    for (int k = 0; k < iters; ++k) {
+        a = fmaf(a, 0.999f, 0.001f * b);
+        b = fmaf(b, 0.998f, 0.002f * __sinf(a));
+        const float cf = a > b ? a : b;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) g[j] = fmaf(cf, b - (float)j * 0.01f, g[j] * 0.99f);
+        if ((k & 63) == 0) d = d * 0.999 + (double)a;
+    }
+    float r = (float)d;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) r += g[j];
+    out[i] = r;
+}
 
 template <class T>
 static T* up(const std::vector<T>& h) {
@@ -50,8 +76,8 @@ static T* up(const std::vector<T>& h) {
 int main(int argc, char** argv) {
     constexpr int L = LV, KIND = KINDV, GS = GSV;
     constexpr bool RES = RESV != 0;
-    using CF = WideCfg<KIND, FMS, FCG, GS, L, RES>;
-    using CB = Bf3Cfg<KIND, BMS, 32, GS, L, RES>;
+    using CF = WideCfg<FKIND, FMS, FCG, GS, L, RES>;
+    using CB = Bf3Cfg<KIND, BMS, BCG, GS, L, RES>;
     constexpr int LOUT = CB::LOUT, NTAP = CB::NTAP;
     static_assert(CF::LOUT == LOUT, "same op");
     const int B = argc > 4 ? atoi(argv[4]) : 1024, C = 8 * GS, Cin = argc > 1 ? atoi(argv[1]) : C;
@@ -75,7 +101,8 @@ int main(int argc, char** argv) {
     for (auto& v : hbe) v = 0.3f * d(g);
     for (auto& v : htb) v = 0.5f * d(g);
     std::vector<float> hWf((size_t)(C / FMS) * (Cin / CF::KG) * CF::NSLAB * 256);
-    pack_fragments(hW.data(), C, Cin, 0, NTAP, RES, hWf.data(), FMS);
+    if (FKIND == WK_K5K4) pack_fragments_k4(hW.data(), C, Cin, RES, hWf.data());
+    else pack_fragments(hW.data(), C, Cin, 0, NTAP, RES, hWf.data(), FMS);
     std::vector<unsigned short> hWb(bf3_stream_elems(C, Cin, CB::NSLOT));
     pack_fragments_bf3(hW.data(), C, Cin, NTAP, RES, hWb.data());
     // device input: one tensor, or two halves [B][L][Cin/2]
@@ -98,8 +125,8 @@ int main(int argc, char** argv) {
     q.dst = y16;
     q.W = reinterpret_cast<const float*>(Wb);
     if (RES) q.res_out = r16;
-    launch_wide_t<KIND, FMS, FCG, GS, L, RES>(p, 0);
-    launch_bf3_t<KIND, BMS, 32, GS, L, RES>(q, 0);
+    launch_wide_t<FKIND, FMS, FCG, GS, L, RES>(p, 0);
+    launch_bf3_t<KIND, BMS, BCG, GS, L, RES>(q, 0);
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); return 1; }
     std::vector<float> h32(nout), h16(nout), hr32(nres), hr16(nres);
@@ -174,19 +201,94 @@ int main(int argc, char** argv) {
     for (int r = 0; r < 6; ++r) {
         float ms;
         hipEventRecord(e0, 0);
-        for (int i = 0; i < 50; ++i) launch_wide_t<KIND, FMS, FCG, GS, L, RES>(p, 0);
+        for (int i = 0; i < 50; ++i) launch_wide_t<FKIND, FMS, FCG, GS, L, RES>(p, 0);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
         best32 = std::min(best32, ms * 20.f);
         hipEventRecord(e0, 0);
-        for (int i = 0; i < 50; ++i) launch_bf3_t<KIND, BMS, 32, GS, L, RES>(q, 0);
+        for (int i = 0; i < 50; ++i) launch_bf3_t<KIND, BMS, BCG, GS, L, RES>(q, 0);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
         best16 = std::min(best16, ms * 20.f);
     }
     printf("  us per launch (chains of 50): fp32-MFMA %.2f | bf16x3 %.2f | x%.3f\n", best32, best16, best32 / best16);
+    {   // co-residency check: the same launch on 4 streams at once (quarter batches, as the sampler's row chains do), many rounds, every output bit-compared with the serial one
+        hipStream_t st[4];
+        float* yo[4];
+        for (int k = 0; k < 4; ++k) { hipStreamCreate(&st[k]); hipMalloc((void**)&yo[k], nout * 4); }
+        size_t bad = 0;
+        std::vector<float> hk(nout);
+        const int Bq = B / 4;
+        for (int round = 0; round < 40; ++round) {
+            for (int k = 0; k < 4; ++k) {
+                RcbP qq = q;
+                qq.B = Bq;
+                qq.src1 = q.src1 + (size_t)k * Bq * L * C1;
+                if (C2) qq.src2 = q.src2 + (size_t)k * Bq * L * C2;
+                qq.dst = yo[k] + (size_t)k * Bq * LOUT * C;
+                if (RES) qq.res_out = r16 + (size_t)k * Bq * L * C;
+                for (int rep = 0; rep < 3; ++rep) launch_bf3_t<KIND, BMS, BCG, GS, L, RES>(qq, st[k]);
+            }
+            hipDeviceSynchronize();
+            for (int k = 0; k < 4; ++k) {
+                hipMemcpy(hk.data(), yo[k], nout * 4, hipMemcpyDeviceToHost);
+                for (size_t i = (size_t)k * Bq * LOUT * C; i < (size_t)(k + 1) * Bq * LOUT * C; ++i) bad += (__builtin_bit_cast(unsigned, hk[i]) != __builtin_bit_cast(unsigned, h16[i]));
+            }
+        }
+        printf("  4 quarter-batch launches on 4 streams x 40 rounds: %zu elements differ from the serial launch\n", bad);
+        // mixed: the bf16x3 kernel on two streams beside the fp32 kernel on two others
+        size_t badb = 0, badf = 0;
+        for (int round = 0; round < 40; ++round) {
+            for (int k = 0; k < 4; ++k) {
+                RcbP qq = (k & 1) ? q : p;
+                qq.B = Bq;
+                qq.src1 = q.src1 + (size_t)k * Bq * L * C1;
+                if (C2) qq.src2 = q.src2 + (size_t)k * Bq * L * C2;
+                qq.dst = yo[k] + (size_t)k * Bq * LOUT * C;
+                if (RES) qq.res_out = ((k & 1) ? r16 : r32) + (size_t)k * Bq * L * C;
+                for (int rep = 0; rep < 3; ++rep) {
+                    if (k & 1) launch_bf3_t<KIND, BMS, BCG, GS, L, RES>(qq, st[k]);
+                    else launch_wide_t<FKIND, FMS, FCG, GS, L, RES>(qq, st[k]);
+                }
+            }
+            hipDeviceSynchronize();
+            for (int k = 0; k < 4; ++k) {
+                hipMemcpy(hk.data(), yo[k], nout * 4, hipMemcpyDeviceToHost);
+                const std::vector<float>& ref = (k & 1) ? h16 : h32;
+                for (size_t i = (size_t)k * Bq * LOUT * C; i < (size_t)(k + 1) * Bq * LOUT * C; ++i) ((k & 1) ? badb : badf) += (__builtin_bit_cast(unsigned, hk[i]) != __builtin_bit_cast(unsigned, ref[i]));
+            }
+        }
+        printf("  mixed (bf16x3 on 2 streams + fp32 on 2 streams) x 40 rounds: bf16x3 outputs differ in %zu elements, fp32 outputs in %zu\n", badb, badf);
+        // canary beside each kernel
+        const int NC = 1024 * 256, IT = 6000;
+        float* cd;
+        hipMalloc((void**)&cd, NC * 4);
+        std::vector<float> c0(NC), c1(NC);
+        hipLaunchKernelGGL(canary_kernel, dim3(NC / 256), dim3(256), 0, st[0], cd, IT, 0.3f);
+        hipDeviceSynchronize();
+        hipMemcpy(c0.data(), cd, NC * 4, hipMemcpyDeviceToHost);
+        for (int which = 0; which < 2; ++which) {
+            size_t badc = 0;
+            int lanes[64] = {0};
+            for (int round = 0; round < 60; ++round) {
+                hipMemsetAsync(cd, 0, NC * 4, st[0]);
+                hipLaunchKernelGGL(canary_kernel, dim3(NC / 256), dim3(256), 0, st[0], cd, IT, 0.3f);
+                for (int rep = 0; rep < 12; ++rep) {
+                    if (which == 0) launch_bf3_t<KIND, BMS, BCG, GS, L, RES>(q, st[1]);
+                    else launch_wide_t<FKIND, FMS, FCG, GS, L, RES>(p, st[1]);
+                }
+                hipDeviceSynchronize();
+                hipMemcpy(c1.data(), cd, NC * 4, hipMemcpyDeviceToHost);
+                for (int i = 0; i < NC; ++i)
+                    if (__builtin_bit_cast(unsigned, c1[i]) != __builtin_bit_cast(unsigned, c0[i])) { ++badc; ++lanes[i & 63]; }
+            }
+            printf("  VALU canary beside the %s kernel x 60 rounds: %zu of %d x 60 results differ from the solo run; lanes hit:", which == 0 ? "bf16x3" : "fp32-MFMA", badc, NC);
+            for (int l = 0; l < 64; ++l) if (lanes[l]) printf(" %d(x%d)", l, lanes[l]);
+            printf("\n");
+        }
+    }
 #ifdef EDMP_BF3_STAMPS
     long long st[8][8];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(edmp::g_bf3_stamps), sizeof(st));
