@@ -42,9 +42,9 @@ def effective_cores() -> int:
 
 
 def pmc_traffic():
-    """HBM MB per conv-family launch from the committed rocprofv3 PMC passes (profiles/r05_pmc_hbm_traffic.json, else
+    """HBM MB per conv-family launch from the committed rocprofv3 PMC passes (profiles/r06_pmc_hbm_traffic.json, else
     an earlier round's; produced by scripts/pmc_unet_forward.py + scripts/summarize_pmc.py).  Counters cannot be read live."""
-    for name in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+    for name in ("r06_pmc_hbm_traffic.json", "r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)["conv_family"]
@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--logical-batch", action="store_true",
                     help="BASELINE config 5 semantics: the ranks hold row shards of ONE reference batch of gpus x batch rows; sum(g^2) is all-reduced "
                          "over RCCL once per guided step from inside the device-resident loop (instead of independent replicas)")
+    ap.add_argument("--hook", choices=("native", "python"), default="native",
+                    help="--logical-batch: the per-guided-step all-reduce as native code (ncclAllReduce called by the device loop, csrc/rccl_hook.hip; "
+                         "needs the nccl backend) or as the Python callback into torch.distributed (round 5; the only choice over gloo)")
     ap.add_argument("--obstacles", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the instrumented (HIP-event) pass")
@@ -151,7 +154,11 @@ def main():
     import functools
 
     # logical-batch mode issues the collective even in a world of one, so that N = 1 measures the hook + RCCL launch cost
-    ar = functools.partial(ED.allreduce_sum_, always=(world > 1 or (dist.is_available() and dist.is_initialized()))) if logical else None
+    ar = None
+    if logical and args.hook == "native" and backend == "nccl":
+        ar = ED.RcclAllReduce(dif)  # own communicator: the unique id travels through the process group once, before the timed region
+    elif logical:
+        ar = functools.partial(ED.allreduce_sum_, always=(world > 1 or (dist.is_available() and dist.is_initialized())))
 
     last = {}
 
@@ -272,10 +279,10 @@ def main():
                                       "672).  rate / best_row_ok = the stricter flag that also requires every waypoint inside the limits.  A geometric stand-in for the "
                                       "reference's pybullet check (lib/environment.py:632-680), which is unavailable offline; random-init denoiser (no trained weights "
                                       "offline): the rates say nothing about planning quality, they are reported, never gated"},
-            # one logical batch: host time of the per-guided-step hook (Python ctypes callback that enqueues the RCCL
-            # all-reduce of sum(g^2) on the context's stream), rank 0, last call
-            "allreduce_hook": (None if not logical else {"calls_per_denoise": dif.hook_stats["calls"], "avg_us": 1e6 * dif.hook_stats["total_s"] / max(dif.hook_stats["calls"], 1),
-                                                        "max_us": 1e6 * dif.hook_stats["max_s"]}),
+            # one logical batch: host time of the per-guided-step hook that enqueues the RCCL all-reduce of sum(g^2) on the context's
+            # stream, measured by the library around each call (edmp_sampler_allreduce_stats), rank 0, last call
+            "allreduce_hook": (None if not logical else {"kind": dif.hook_stats["kind"], "calls_per_denoise": dif.hook_stats["calls"],
+                                                        "avg_us": 1e6 * dif.hook_stats["total_s"] / max(dif.hook_stats["calls"], 1), "max_us": 1e6 * dif.hook_stats["max_s"]}),
             "unet_flops_per_traj_step": {"nominal": nominal, "direct_form_after_tap_skipping": net.flops_direct_form(), "issued_mfma_fp32_equivalent": executed,
                                          "issued_on_the_fp32_pipe": f32_bf16[0], "issued_on_the_bf16_pipe": f32_bf16[1], "survey": SURVEY_FLOPS_PER_TRAJ_STEP,
                                          "note": "issued (fp32 equivalent) < direct form: the L=2 / L=4 Conv1dBlocks run in Karatsuba form (3 of 4 resp. 9 of 14 matrix products); the bf16x3 layers "

@@ -84,6 +84,14 @@ SIGNATURES = {
     "edmp_guide_slot": (_i, [_vp, C.c_uint64]),
     "edmp_argmin_dev": (_i, [_vp, _vp, _i, C.POINTER(C.c_int)]),
     "edmp_sampler_set_allreduce": (_i, [_vp, _vp, _vp]),
+    "edmp_rccl_load": (_i, [C.c_char_p]),
+    "edmp_rccl_unique_id": (_i, [_vp]),
+    "edmp_rccl_attach": (_i, [_vp, _vp, _i, _i]),
+    "edmp_rccl_attach_comm": (_i, [_vp, _vp]),
+    "edmp_rccl_enable": (_i, [_vp, _i]),
+    "edmp_rccl_detach": (_i, [_vp]),
+    "edmp_rccl_info": (_i, [_vp, _pi32]),
+    "edmp_sampler_allreduce_stats": (_i, [_vp, C.POINTER(C.c_uint64), _i]),
     "edmp_prof_enable": (_i, [_vp, _i]),
     "edmp_prof_read": (_i, [_vp, _pd, C.POINTER(C.c_int64), _i]),
     "edmp_prof_ops": (_i, [_vp, _i, C.POINTER(C.c_int), _pd, C.POINTER(C.c_int64), _pd, C.c_char_p]),

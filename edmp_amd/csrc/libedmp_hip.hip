@@ -6,3 +6,4 @@
 #include "unet.hip"
 #include "guide.hip"
 #include "sampler.hip"
+#include "rccl_hook.hip"

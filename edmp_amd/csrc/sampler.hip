@@ -46,11 +46,12 @@ struct Sampler {
     // call's arguments stay the same (start/goal travel through `sg`, so they are not part of the key)
     struct GraphKey {
         const void* noise = nullptr;
+        const void* hook = nullptr;  // the (native) all-reduce hook's communicator record the capture contains, or null
         uint64_t seed = 0;
         int use_rng = 0, B = 0, guided = 0, t_hi = 0, t_lo = 0, init = 0, zero_row0 = 0, condition = 0;
         uint64_t epoch = 0;  // bumped by anything that invalidates captured pointers/arguments (scene, rows, weights)
         bool operator==(const GraphKey& o) const {
-            return noise == o.noise && seed == o.seed && use_rng == o.use_rng && B == o.B && guided == o.guided && t_hi == o.t_hi &&
+            return noise == o.noise && hook == o.hook && seed == o.seed && use_rng == o.use_rng && B == o.B && guided == o.guided && t_hi == o.t_hi &&
                    t_lo == o.t_lo && init == o.init && zero_row0 == o.zero_row0 && condition == o.condition && epoch == o.epoch;
         }
     } gkey;
@@ -63,6 +64,8 @@ struct Sampler {
     // loop to sum the device scalar sum(g^2) over ranks (lib/guide.py:629 is the only coupling between rows)
     edmp_allreduce_fn ar_fn = nullptr;
     void* ar_user = nullptr;
+    struct RcclHook* rccl = nullptr;              // rccl_hook.hip: the native hook's communicator, when that hook is installed
+    uint64_t ar_calls = 0, ar_ns = 0, ar_max_ns = 0;  // host time spent inside the hook (edmp_sampler_allreduce_stats)
     // Row chains of ONE batch (edmp_sampler_set_chains): the device-resident loop runs the batch as `chains` contiguous row
     // ranges, each on its own stream.  Rows only meet in the whole-batch sum(g^2) of a guided step (lib/guide.py:629): every
     // chain's guide kernel writes its rows' partial sums into the step's buffer (two buffers, alternating per guided step, so a
@@ -84,8 +87,12 @@ struct Span {
     bool whole() const { return r0 == 0 && n == B; }
 };
 
+void sampler_rccl_destroy(Sampler* s);            // rccl_hook.hip
+bool sampler_hook_is_native(const Sampler* s);    // rccl_hook.hip: the installed hook is the stream-capturable ncclAllReduce one
+
 void sampler_destroy(Sampler* s) {
     if (!s) return;
+    sampler_rccl_destroy(s);
     for (void* p : {(void*)s->X, (void*)s->sg, (void*)s->qcoef})
         if (p) (void)hipFree(p);
     if (s->gexec) (void)hipGraphExecDestroy(s->gexec);
@@ -790,7 +797,12 @@ static int enqueue_loop(edmp_ctx* ctx, const double* noise_dev, bool use_rng, ui
         if (s->ar_fn && guided && guided_step(t)) {
             // sharded logical batch: this rank's sum(g^2) -> the whole batch's, enqueued by the caller's collective on
             // the context's stream (stream order is the only synchronisation: no host round trip)
+            timespec h0, h1;
+            clock_gettime(CLOCK_MONOTONIC, &h0);
             rc = s->ar_fn(s->ar_user, (void*)st, guide_sumsq(ctx));
+            clock_gettime(CLOCK_MONOTONIC, &h1);
+            const uint64_t ns = (uint64_t)((h1.tv_sec - h0.tv_sec) * 1000000000ll + (h1.tv_nsec - h0.tv_nsec));
+            s->ar_calls++, s->ar_ns += ns, s->ar_max_ns = ns > s->ar_max_ns ? ns : s->ar_max_ns;
             if (rc) {
                 set_error("allreduce hook failed with status %d at step t=%d", rc, t);
                 return EDMP_ERR_STATE;
@@ -832,14 +844,14 @@ static int denoise_loop(edmp_ctx* ctx, const double* noise_dev, bool use_rng, ui
     }
     // a caller-supplied collective is not capturable; segments of a chunked run carry a fresh noise pointer each, so a
     // captured graph would never be replayed (capture + instantiate + destroy per chunk): they are enqueued directly
-    const bool graph = allow_graph && s->graph_on == 1 && !ctx->prof.on && !s->ar_fn && loop_chains(ctx, B, guided) == 1;
+    const bool graph = allow_graph && s->graph_on == 1 && !ctx->prof.on && (!s->ar_fn || sampler_hook_is_native(s)) && loop_chains(ctx, B, guided) == 1;
     Sampler::GraphKey key;
     if (graph) {
         if (guided) {
             rc = guide_prepare(ctx, B, N - 2);
             if (rc) return rc;
         }
-        key.noise = noise_dev, key.seed = seed, key.use_rng = use_rng, key.B = B, key.guided = guided, key.t_hi = t_hi, key.t_lo = t_lo;
+        key.noise = noise_dev, key.hook = s->ar_fn ? s->ar_user : nullptr, key.seed = seed, key.use_rng = use_rng, key.B = B, key.guided = guided, key.t_hi = t_hi, key.t_lo = t_lo;
         key.init = init, key.zero_row0 = zero_row0, key.condition = s->condition, key.epoch = ctx->epoch;
         if (s->gexec && key == s->gkey) {
             s->graph_replays++;

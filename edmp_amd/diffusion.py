@@ -139,9 +139,9 @@ class Diffusion:
                        chains=None):
         """diffusion.py:300-356.  ``noise``: optional pre-drawn (T+1,B,C,N) f64 ndarray / device tensor (default:
         drawn from the global NumPy RNG in the reference's order); ``noise="device"`` draws z on the GPU (Philox,
-        ``seed``) — a non-parity mode without the host draw / upload.  ``allreduce(tensor)``: this call is one row shard
-        of a batch spread over several GPUs; the callable sums the f64 device scalar over ranks in place (see
-        edmp_amd.dist.allreduce_sum_).  ``chains`` (default: the diffuser's ``self.chains``, 1): run the batch as that many
+        ``seed``) — a non-parity mode without the host draw / upload.  ``allreduce``: this call is one row shard
+        of a batch spread over several GPUs; an ``edmp_amd.dist.RcclAllReduce`` (native ncclAllReduce inside the device loop) or a
+        callable that sums the f64 device scalar over ranks in place (edmp_amd.dist.allreduce_sum_; a Python callback per guided step).  ``chains`` (default: the diffuser's ``self.chains``, 1): run the batch as that many
         row-sharded chains on separate HIP streams (edmp_sampler_set_chains) - bit-identical results, see include/edmp_hip.h.
         Returns (B,C,N) f64 ndarray (a fresh copy)."""
         ctx = self.ctx
@@ -164,21 +164,34 @@ class Diffusion:
             # context's stream and the device scalar, the collective is ordered by the stream (no host round trip)
             if noise is None or isinstance(noise, str):
                 raise ValueError("sharded runs take an explicit noise array (this rank's rows of the global stream)")
+            from .dist import RcclAllReduce
+
+            def _read_stats():
+                raw = (C.c_uint64 * 3)()
+                _capi.check(ctx.lib.edmp_sampler_allreduce_stats(ctx.h, raw, 1))
+                # host time inside the hook, measured by the library around each call (any hook): GIL + collective enqueue
+                self.hook_stats = dict(calls=int(raw[0]), total_s=1e-9 * int(raw[1]), max_s=1e-9 * int(raw[2]),
+                                       kind="native ncclAllReduce (csrc/rccl_hook.hip)" if native else "python callback (ctypes -> torch.distributed)")
+
+            native = isinstance(allreduce, RcclAllReduce)
+            if native:
+                # the hook is native code installed once on this context (csrc/rccl_hook.hip): nothing to install per call
+                if allreduce.ctx is not ctx or not allreduce.attached():
+                    raise ValueError("this RcclAllReduce is not attached to the diffuser's context (or was closed)")
+                _capi.check(ctx.lib.edmp_rccl_enable(ctx.h, 1), "edmp_rccl_enable")
+                _read_stats()
+                try:
+                    return self.denoise_guided(model, guide, traj_len, num_channels, guidance_schedule, batch_size, start, goal, condition, benchmarking,
+                                               noise=noise, seed=seed, t_stop=t_stop, zero_row0=zero_row0, return_device=return_device, chains=chains)
+                finally:
+                    _capi.check(ctx.lib.edmp_rccl_enable(ctx.h, 0), "edmp_rccl_enable")  # other runs of this context are not shards
+                    _read_stats()
             sumsq = self.sumsq_tensor()
-
-            import time as _time
-
-            stats = self.hook_stats = dict(calls=0, total_s=0.0, max_s=0.0)  # host time spent in the hook (GIL + collective enqueue)
 
             def _hook(_user, _stream, _ptr):
                 try:
-                    t0 = _time.perf_counter()
                     with torch.cuda.stream(ctx.stream):  # RCCL orders itself after the gradient kernels / before step_b
                         allreduce(sumsq)
-                    dt = _time.perf_counter() - t0
-                    stats["calls"] += 1
-                    stats["total_s"] += dt
-                    stats["max_s"] = max(stats["max_s"], dt)
                     return 0
                 except Exception as exc:  # surfaced by the C side as EDMP_ERR_STATE
                     self._hook_error = exc
@@ -187,6 +200,7 @@ class Diffusion:
             cb = _capi.ALLREDUCE_FN(_hook)
             self._hook_error = None
             _capi.check(ctx.lib.edmp_sampler_set_allreduce(ctx.h, C.cast(cb, C.c_void_p), None))
+            _read_stats()
             try:
                 res = self.denoise_guided(model, guide, traj_len, num_channels, guidance_schedule, batch_size, start, goal, condition, benchmarking,
                                           noise=noise, seed=seed, t_stop=t_stop, zero_row0=zero_row0, return_device=return_device, chains=chains)
@@ -196,6 +210,7 @@ class Diffusion:
                 raise
             finally:
                 _capi.check(ctx.lib.edmp_sampler_set_allreduce(ctx.h, None, None))
+                _read_stats()
             return res
         if isinstance(noise, str):
             if noise != "device":

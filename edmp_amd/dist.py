@@ -84,6 +84,71 @@ def allreduce_sum_(t: torch.Tensor, group=None, always=False):
     return t
 
 
+def _rccl_library_path():
+    """the librccl the process already mapped (PyTorch-ROCm ships one beside libtorch_hip.so), from /proc/self/maps; None if none"""
+    try:
+        for line in open("/proc/self/maps"):
+            path = line.rsplit(None, 1)[-1]
+            if "/librccl.so" in path:
+                return path
+    except OSError:
+        pass
+    return None
+
+
+class RcclAllReduce:
+    """The per-guided-step all-reduce as NATIVE code (csrc/rccl_hook.hip): ``dif.denoise_guided(allreduce=RcclAllReduce(dif))``
+    lets the device-resident loop call ncclAllReduce itself - no Python callback, no GIL, on the loop's path (the callable form
+    ``allreduce=dist.allreduce_sum_`` stays: gloo test boxes, other collectives).
+
+    One communicator per context, created ONCE: rank 0 draws the ncclUniqueId, the 128 bytes travel through the default
+    torch.distributed group (any backend), every rank calls ncclCommInitRank on its context's device.  ``comm_ptr``: borrow an
+    existing communicator instead (torch: ``pg._get_backend(torch.device("cuda"))._comm_ptr()``).  In a world of one (or with
+    no process group) the communicator has one rank: the collective is still issued, which is what N = 1 measures."""
+
+    def __init__(self, diffusion, group=None, comm_ptr=None, library=None):
+        import ctypes as C
+
+        from . import _capi
+
+        ctx = diffusion.ctx  # (a Diffusion: the sampler state the hook lives in is created from its T / variance threshold)
+        ctx.ensure_sampler(diffusion.T, diffusion.variance_thresh)
+        self.ctx, self.lib = ctx, ctx.lib
+        _capi.check(self.lib.edmp_rccl_load((library or _rccl_library_path() or "").encode() or None), "edmp_rccl_load")
+        if comm_ptr is not None:
+            _capi.check(self.lib.edmp_rccl_attach_comm(ctx.h, C.c_void_p(int(comm_ptr))), "edmp_rccl_attach_comm")
+        else:
+            on = dist.is_available() and dist.is_initialized()
+            world = dist.get_world_size(group) if on else 1
+            rank = dist.get_rank(group) if on else 0
+            buf = C.create_string_buffer(128)
+            if rank == 0:
+                _capi.check(self.lib.edmp_rccl_unique_id(buf), "edmp_rccl_unique_id")
+            box = [bytes(buf.raw)]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+            ident = C.create_string_buffer(box[0], 128)
+            with torch.cuda.device(ctx.device):
+                _capi.check(self.lib.edmp_rccl_attach(ctx.h, ident, world, rank), "edmp_rccl_attach")
+        info = (C.c_int32 * 3)()
+        _capi.check(self.lib.edmp_rccl_info(ctx.h, info))
+        self.world, self.rank, self.kind = int(info[0]), int(info[1]), {1: "own communicator", 2: "borrowed communicator"}[int(info[2])]
+        _capi.check(self.lib.edmp_rccl_enable(ctx.h, 0))  # denoise_guided(allreduce=self) switches it on for its own run only
+
+    def attached(self) -> bool:
+        import ctypes as C
+
+        info = (C.c_int32 * 3)()
+        self.lib.edmp_rccl_info(self.ctx.h, info)
+        return int(info[2]) != 0
+
+    def close(self):
+        from . import _capi
+
+        if self.ctx.h:
+            _capi.check(self.lib.edmp_rccl_detach(self.ctx.h), "edmp_rccl_detach")
+
+
 def geometric_success(volume: float, traj, lo=None, hi=None) -> bool:
     """success PROXY (pybullet is not available): zero t=0 swept volume and all waypoints inside the joint limits
     (SURVEY.md §8d).  Not the paper's success rate."""

@@ -231,9 +231,34 @@ int edmp_guide_slot(edmp_ctx* ctx, uint64_t key);
  * device-resident loop calls `fn(user, hip_stream, sumsq_dev)` once per guided step, between the gradient kernels
  * and the state update: the callee must enqueue, ON THAT STREAM, an in-place sum over ranks of the f64 device scalar
  * (e.g. ncclAllReduce / torch.distributed.all_reduce with that stream current) and return 0.  fn = NULL (default)
- * restores the single-GPU behaviour.  hipGraph replay is disabled while a hook is installed. */
+ * restores the single-GPU behaviour.  hipGraph replay is disabled while a caller hook is installed (an arbitrary callee is not
+ * capturable; the native RCCL hook below is). */
 typedef int (*edmp_allreduce_fn)(void* user, void* hip_stream, double* sumsq_dev);
 int edmp_sampler_set_allreduce(edmp_ctx* ctx, edmp_allreduce_fn fn, void* user);
+
+/* The hook as native code (csrc/rccl_hook.hip): one ncclAllReduce of the f64 scalar on the context's stream per guided step - no
+ * Python / GIL inside the device-resident loop (the round-5 hook was a ctypes callback into torch.distributed.all_reduce:
+ * edmp_amd/diffusion.py; it stays available through edmp_sampler_set_allreduce).  RCCL is resolved at run time, never linked:
+ *   edmp_rccl_load(path)       path = NULL: the RCCL already in the process (the one torch brought), else librccl.so.1; or a path
+ *   edmp_rccl_unique_id(id)    ncclGetUniqueId into 128 caller bytes: one rank calls it and hands the bytes to the others by any
+ *                              means (torch.distributed.broadcast_object_list over gloo or nccl, MPI, a file)
+ *   edmp_rccl_attach(ctx, id, nranks, rank)   ncclCommInitRank on the context's device (collective over the ranks), installs the hook
+ *   edmp_rccl_attach_comm(ctx, comm)          borrow a communicator the host already has (torch: ProcessGroupNCCL._comm_ptr())
+ *   edmp_rccl_enable(ctx, on)  attach leaves the hook ON; 0 switches the collective off and keeps the communicator (runs of this
+ *                              context that are NOT shards of one logical batch), 1 switches it on again
+ *   edmp_rccl_detach(ctx)      remove the hook, destroy an owned communicator (also done by edmp_ctx_destroy).  edmp_sampler_set_allreduce
+ *                              replaces the ACTIVE hook only; an attached communicator stays and edmp_rccl_enable brings it back
+ *   edmp_rccl_info(ctx, out)   out = {nranks, rank, 0 none | 1 own communicator | 2 borrowed}
+ * ncclAllReduce is stream-capturable: whole-run hipGraph replay (edmp_sampler_set_graph) stays legal with THIS hook installed.
+ * edmp_sampler_allreduce_stats: host time spent inside the hook (any hook) since the last reset: {calls, total ns, max ns}. */
+int edmp_rccl_load(const char* path);
+int edmp_rccl_unique_id(void* id128);
+int edmp_rccl_attach(edmp_ctx* ctx, const void* id128, int nranks, int rank);
+int edmp_rccl_attach_comm(edmp_ctx* ctx, void* nccl_comm);
+int edmp_rccl_enable(edmp_ctx* ctx, int on);
+int edmp_rccl_detach(edmp_ctx* ctx);
+int edmp_rccl_info(edmp_ctx* ctx, int32_t out[3]);
+int edmp_sampler_allreduce_stats(edmp_ctx* ctx, uint64_t out[3], int reset);
 
 /* ---- instrumentation ----------------------------------------------------------------------------------- */
 /* accumulate HIP-event time of the dominant kernel family (the MFMA conv kernels of the UNet layer program) while enabled:

@@ -5,7 +5,7 @@ R=${1:-r05}
 O=gpurun_out/$R
 set -e
 cp $O/bench.json profiles/${R}_bench.json
-for c in c2 c5_n1; do [ -s $O/bench_$c.json ] && grep '^{' $O/bench_$c.json | tail -1 > profiles/${R}_bench_$c.json; done  # (RCCL prints its version banner on stdout: the JSON line is the one that starts with a brace)
+for c in c2 c5_n1 c5_n1_pyhook; do [ -s $O/bench_$c.json ] && grep '^{' $O/bench_$c.json | tail -1 > profiles/${R}_bench_$c.json; done  # (RCCL prints its version banner on stdout: the JSON line is the one that starts with a brace)
 python - <<EOF
 import json
 b = json.load(open('$O/bench.json'))

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Run on the GPU box by gpurun: bench.py, the rocprofv3 kernel trace of the same command, and the PMC passes
-# (FETCH_SIZE / WRITE_SIZE / MFMA busy, each its own run, --kernel-trace only).  Outputs -> gpurun_out/\$ROUND/ (default r05); raw
+# (FETCH_SIZE / WRITE_SIZE / MFMA busy, each its own run, --kernel-trace only).  Outputs -> gpurun_out/\$ROUND/ (default r06); raw
 # output stays there untouched, scripts/collect_round.sh copies the summaries into profiles/ and derives profiles/<round>_numbers.md.
-O=gpurun_out/${ROUND:-r05}
+O=gpurun_out/${ROUND:-r06}
 mkdir -p $O
 python bench.py --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err
 python scripts/show_bench.py $O/bench.json | cut -c1-220 | head -4
@@ -10,9 +10,10 @@ python scripts/show_bench.py $O/bench.json | cut -c1-220 | head -4
 # one logical batch in an RCCL world of one (the per-guided-step all-reduce really issued)
 python bench.py --guides 1,2,3 --steps 3 --warmup 1 --no-cpu-baseline --no-two-scenes --no-problem-set > $O/bench_c2.json 2> $O/bench_c2.err
 python bench.py --guides 1,2,3,4,5,10,11,13 --logical-batch --steps 3 --warmup 1 --no-cpu-baseline --no-two-scenes --no-problem-set > $O/bench_c5_n1.json 2> $O/bench_c5_n1.err
+python bench.py --guides 1,2,3,4,5,10,11,13 --logical-batch --hook python --steps 3 --warmup 1 --no-cpu-baseline --no-two-scenes --no-problem-set --no-roofline --no-native-leg > $O/bench_c5_n1_pyhook.json 2> $O/bench_c5_n1_pyhook.err
 export TMPDIR=/tmp
 REPO=$PWD
-CMD="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-two-scenes --no-problem-set"  # (two scenes in flight would overlap kernels of two contexts: durations in the trace would no longer be one chain's)
+CMD="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-two-scenes --no-problem-set --no-native-leg"  # (two scenes in flight would overlap kernels of two contexts: durations in the trace would no longer be one chain's)
 cd /tmp
 rm -rf $REPO/$O/prof $REPO/$O/pmc_*
 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$O/prof -o trace -- $CMD > $REPO/$O/prof_bench.json 2> $REPO/$O/prof.err

@@ -38,12 +38,12 @@ if ps:
             split = ", ".join(f"{k[:-2]} {1e3 * v:.1f} ms" for k, v in q["per_scene_split_s_mean"].items())
             print(f"* problem set ({ps['scenes']} scenes x {ps['rows_per_scene']} rows, {key}): {q['scenes_per_s']:.2f} scenes/s = {q['traj_steps_per_s']:.0f} traj-steps/s (steady state {q.get('steady_state_traj_steps_per_s', float('nan')):.0f}); "
                   f"planning time {1e3 * q['planning_time_s_mean']:.1f} ms per scene: {split}")
-for tag in ("c2", "c5_n1"):
+for tag in ("c2", "c5_n1", "c5_n1_pyhook"):
     fp = os.path.join(P, f"{R}_bench_{tag}.json")
     if os.path.exists(fp):
         q = json.load(open(fp))
         print(f"* `{R}_bench_{tag}.json`: {q['value']:.0f} {q['unit']}, ms_per_step {q['ms_per_step']:.2f}, roofline frac {q.get('roofline', {}).get('frac', float('nan')):.3f} - {q['config']['workload'][:110]}"
-              + (f"; all-reduce hook {q['allreduce_hook']['avg_us']:.1f} us avg x {q['allreduce_hook']['calls_per_denoise']} calls" if q.get("allreduce_hook") else ""))
+              + (f"; all-reduce hook ({q['allreduce_hook'].get('kind', 'python callback')}) {q['allreduce_hook']['avg_us']:.1f} us avg x {q['allreduce_hook']['calls_per_denoise']} calls" if q.get("allreduce_hook") else ""))
 c = b.get("cpu_baseline")
 if c:
     print(f"* cpu_baseline ({c['kind']}): {c['value']:.0f} {c['unit']} on {c['cores']} cores; {c['sample']}")

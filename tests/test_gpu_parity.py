@@ -1213,6 +1213,7 @@ def test_one_logical_batch_sharded_over_two_ranks():
 
 
 def _nccl_worker(rank, world, port, q):
+    import ctypes as C
     import functools
     import os
 
@@ -1250,7 +1251,35 @@ def _nccl_worker(rank, world, port, q):
         noise = np.ascontiguousarray(noise_for(41, Btot)[:, lo:hi])
         X = dif.denoise_guided(net, guide, 50, 7, sh["guidance_schedule"], batch_size=hi - lo, start=scenes.DEFAULT_START, goal=scenes.DEFAULT_GOAL,
                                noise=noise, t_stop=T - 10, zero_row0=(rank == 0), allreduce=functools.partial(ED.allreduce_sum_, always=True))
-        q.put(("ok", rank, float(x.item()), best["rank"], best["index"], best["volume"], float(best["traj"][0, 0]), lo, hi, X))
+        # the same run with the NATIVE hook (csrc/rccl_hook.hip: ncclAllReduce called by the device loop itself, own communicator from a
+        # unique id broadcast over the process group), with torch's communicator borrowed, and under whole-run hipGraph replay
+        kw = dict(batch_size=hi - lo, start=scenes.DEFAULT_START, goal=scenes.DEFAULT_GOAL, noise=noise, t_stop=T - 10, zero_row0=(rank == 0))
+        py_stats = dict(dif.hook_stats)
+        hook = ED.RcclAllReduce(dif)
+        Xn = dif.denoise_guided(net, guide, 50, 7, sh["guidance_schedule"], allreduce=hook, **kw)
+        extra = {"python": py_stats, "native": dict(dif.hook_stats), "native_world": (hook.world, hook.rank, hook.kind), "X_native": Xn}
+        # the hook is off outside its own runs: an unsharded run of the same context must not issue the collective
+        dif.denoise_guided(net, guide, 50, 7, sh["guidance_schedule"], **kw)
+        raw = (C.c_uint64 * 3)()
+        dif.ctx.lib.edmp_sampler_allreduce_stats(dif.ctx.h, raw, 1)
+        extra["calls_of_an_unsharded_run"] = int(raw[0])
+        dif.ctx.lib.edmp_sampler_set_graph(dif.ctx.h, 1)
+        noise_dev = dif.ctx.to_dev(noise, torch.float64)  # (graph replay keys on the resident noise pointer)
+        kw["noise"] = noise_dev
+        Xg = [dif.denoise_guided(net, guide, 50, 7, sh["guidance_schedule"], allreduce=hook, **kw) for _ in range(3)]
+        dif.ctx.lib.edmp_sampler_set_graph(dif.ctx.h, 0)
+        extra["X_graph"] = Xg[-1]
+        kw["noise"] = noise
+        hook.close()
+        try:
+            comm = dist.distributed_c10d._get_default_group()._get_backend(torch.device(DEV))._comm_ptr()
+            hb = ED.RcclAllReduce(dif, comm_ptr=comm)
+            extra["X_borrowed"] = dif.denoise_guided(net, guide, 50, 7, sh["guidance_schedule"], allreduce=hb, **kw)
+            extra["borrowed_world"] = (hb.world, hb.rank, hb.kind)
+            hb.close()
+        except AttributeError as exc:  # a torch without ProcessGroupNCCL._comm_ptr
+            extra["borrowed_skipped"] = repr(exc)
+        q.put(("ok", rank, float(x.item()), best["rank"], best["index"], best["volume"], float(best["traj"][0, 0]), lo, hi, extra, X))
         dist.destroy_process_group()
     except Exception as exc:  # reported to the parent: a second rank on the same GPU is refused by RCCL
         q.put(("error", rank, repr(exc)))
@@ -1295,8 +1324,16 @@ def test_rccl_branch_world_size_one():
 
     out = _spawn(_nccl_worker, 1)
     assert out[0][0] == "ok", out[0]
-    _, rank, x, brank, bidx, bvol, t00, lo, hi, X = out[0]
+    _, rank, x, brank, bidx, bvol, t00, lo, hi, extra, X = out[0]
     assert x == 2.5 and (brank, bidx, bvol, t00) == (0, 5, 3.0, 0.0)
+    # the native hook: same result bit for bit, one call per guided step (t = 255..246: 5 even steps), off outside its runs
+    assert np.array_equal(extra["X_native"], X) and np.array_equal(extra["X_graph"], X)
+    assert extra["native_world"] == (1, 0, "own communicator") and extra["native"]["calls"] == extra["python"]["calls"] == 5
+    assert extra["native"]["kind"].startswith("native") and extra["python"]["kind"].startswith("python")
+    assert extra["calls_of_an_unsharded_run"] == 0
+    if "X_borrowed" in extra:
+        assert np.array_equal(extra["X_borrowed"], X) and extra["borrowed_world"] == (1, 0, "borrowed communicator")
+    print(f"hook host time per call: python {1e6 * extra['python']['total_s'] / 5:.1f} us, native {1e6 * extra['native']['total_s'] / 5:.1f} us")
     cfgs = cfgs_for([1, 11, 18, 10], 3)
     B = cfgs["total_batch_size"]
     assert (lo, hi) == (0, B)
@@ -1329,6 +1366,10 @@ def test_rccl_two_ranks():
     assert [o[0] for o in out] == ["ok", "ok"] and out[0][2] == out[1][2] == 6.0  # 2.5 + 3.5
     assert (out[0][3], out[0][4], out[0][5], out[0][6]) == (out[1][3], out[1][4], out[1][5], out[1][6]) == (1, 6, 2.0, 1.0)  # rank 1 holds the smaller volume
     Xsh = np.concatenate([out[0][-1], out[1][-1]])
+    for key in ("X_native", "X_graph", "X_borrowed"):  # the native hook sums the same two f64 partials: identical to the Python hook's run
+        if key in out[0][9]:
+            assert np.array_equal(np.concatenate([out[0][9][key], out[1][9][key]]), Xsh), key
+    assert out[0][9]["native_world"] == (2, 0, "own communicator") and out[1][9]["native_world"] == (2, 1, "own communicator")
     assert Xsh.shape[0] == B and (out[0][7], out[0][8], out[1][7], out[1][8]) == (0, B // 2, B // 2, B)
     net = TemporalUNet(None, 7, 32, DEV, dims=TINY_DIMS, state_dict=W.init_state_dict(5, 7, 32, TINY_DIMS), max_batch=B)
     guide = IntersectionVolumeGuide(scenes.random_scene(7, 8), DEV, cfgs, B)
