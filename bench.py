@@ -46,9 +46,14 @@ def pmc_traffic():
     an earlier round's; produced by scripts/pmc_unet_forward.py + scripts/summarize_pmc.py).  Counters cannot be read live."""
     for name in ("r06_pmc_hbm_traffic.json", "r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
         try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                d = json.load(f)["conv_family"]
-            return {"hbm_MB_per_launch": d["hbm_MB_per_launch"], "hbm_bytes_per_traj_step": d["hbm_bytes_per_traj_step"], "source": f"profiles/{name} (PMC pass, not live)"}
+            with open(os.path.join(ROOT, "profiles", name), "rb") as f:
+                raw = f.read()
+            d = json.loads(raw)["conv_family"]
+            import hashlib
+
+            blob = hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest()  # = `git hash-object`: which committed file this number is
+            return {"hbm_MB_per_launch": d["hbm_MB_per_launch"], "hbm_bytes_per_traj_step": d["hbm_bytes_per_traj_step"], "source": f"profiles/{name} (PMC pass, not live)",
+                    "source_git_blob": blob}
         except Exception:
             continue
     return None
@@ -79,7 +84,7 @@ def main():
     ap.add_argument("--no-two-scenes", action="store_true", help="skip the informative two-scenes-in-flight measurement")
     ap.add_argument("--no-native-leg", action="store_true", help="skip the A/B leg with every conv on the fp32-MFMA kernels (value_native_f32)")
     ap.add_argument("--no-problem-set", action="store_true", help="skip the informative problem-set measurement (16 distinct scenes through infer_serial.run)")
-    ap.add_argument("--chains", type=int, default=int(os.environ.get("EDMP_CHAINS", "1")),
+    ap.add_argument("--chains", type=int, default=1,
                     help="run the one batch as this many row-sharded chains on separate HIP streams (edmp_sampler_set_chains; bit-identical results)")
     args = ap.parse_args()
 

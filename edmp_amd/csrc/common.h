@@ -73,8 +73,6 @@ struct edmp_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipStream_t side_stream = nullptr;  // independent branch of the UNet (residual 1x1 convs) runs here
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     edmp::UNet* unet = nullptr;    // the CURRENT model (slot unet_key)
     edmp::Guide* guide = nullptr;  // the CURRENT scene + rows (slot guide_key)
     // resident, not current, most recently used first: a caller that alternates between a few models / per-scene guides

@@ -34,7 +34,6 @@ struct Guide {
     float* startgoal = nullptr;  // [14] f32
     int scratch_B = 0, scratch_L = 0;
     float* vol_rows = nullptr;  // [B] for best trajectory
-    bool split4 = true;         // gradient kernel: four waves per row (guide_kernel<GM_GRAD, ., 4>); EDMP_GUIDE_SPLIT=1 at creation selects one wave per row
     int32_t* flags = nullptr;   // [3][flags_B] success check: ok, first colliding waypoint, within limits; + [4] counts
     int flags_B = 0;
 };

@@ -568,13 +568,11 @@ static int launch_guide(edmp_ctx* ctx, const TIn* joints, int ldw, int off, int 
     a.row0 = row0;
     hipStream_t st = run_stream ? run_stream : ctx->stream;
     if constexpr (MODE == GM_GRAD) {
-        if (g->split4) {  // (EDMP_GUIDE_SPLIT, read when the guide object was created)
-            hipLaunchKernelGGL((guide_kernel<MODE, TIn, 4>), dim3(n - row0), dim3(256), 0, st, a, g->rc);
-            EDMP_HIP_CHECK(hipGetLastError());
-            return EDMP_OK;
-        }
+        // the gradient: four waves per row, one per link group (round 5: 44 -> 28 us per launch against one wave per row)
+        hipLaunchKernelGGL((guide_kernel<MODE, TIn, 4>), dim3(n - row0), dim3(256), 0, st, a, g->rc);
+    } else {
+        hipLaunchKernelGGL((guide_kernel<MODE, TIn, 1>), dim3((n - row0 + 3) / 4), dim3(256), 0, st, a, g->rc);
     }
-    hipLaunchKernelGGL((guide_kernel<MODE, TIn, 1>), dim3((n - row0 + 3) / 4), dim3(256), 0, st, a, g->rc);
     EDMP_HIP_CHECK(hipGetLastError());
     return EDMP_OK;
 }
@@ -655,10 +653,6 @@ extern "C" int edmp_scene_set(edmp_ctx* ctx, const double* obstacle_config, int 
     // null-stream copy - a scene change on one context must not wait for another context's queued loop, see common.h)
     if (!ctx->guide) {
         ctx->guide = new Guide();
-        {   // EDMP_GUIDE_SPLIT=1: the one-wave-per-row layout for the gradient too (A/B runs); frozen into the object like the model builder's switches
-            const char* e = getenv("EDMP_GUIDE_SPLIT");
-            ctx->guide->split4 = !(e && e[0] == '1');
-        }
         if (int rc = ctx_alloc(ctx, (void**)&ctx->guide->sumsq, sizeof(double))) return rc;
         if (int rc = ctx_alloc(ctx, (void**)&ctx->guide->startgoal, 14 * sizeof(float))) return rc;
         EDMP_HIP_CHECK(hipMemsetAsync(ctx->guide->startgoal, 0, 14 * sizeof(float), ctx->stream));

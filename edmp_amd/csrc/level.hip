@@ -173,11 +173,6 @@ __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* o
             for (int u = 0; u < NIT; ++u) in_commit(FIRSTCH, u, vin[u]);
         }
     }
-    if (p.stagger_cycles > 0 && ((blockIdx.x >> p.stagger_bit) & 1)) {
-        // (the input and the first weight fragments are already on their way / in LDS: the wait costs the late workgroup nothing but time)
-        const long long t0 = clock64();
-        while (clock64() - t0 < p.stagger_cycles) __builtin_amdgcn_s_sleep(4);
-    }
     __syncthreads();
 
     EDMP_STAMP(LVSLOT, 1)

@@ -73,10 +73,6 @@ struct LevelP {
     float* out;       // [B][LOUT][C] (LV_UP_FINAL: the final Conv1dBlock's output at the up-sampled length)
     int B;
     TailP tail;       // LV_UP_FINAL in the device-resident loop: head 1x1 conv + posterior step on the tile still in LDS (tail.h)
-    // phase offset between the two workgroups that share a CU (SB = 2 instances): workgroups whose id has bit `stagger_bit` set
-    // wait `stagger_cycles` shader cycles before their first stage, so that one workgroup's GroupNorm / Mish epilogues (VALU) run
-    // under the other's MFMA phases systematically instead of by chance; 0 = off
-    int stagger_cycles = 0, stagger_bit = 0;
 };
 
 #ifdef EDMP_STAMPS  // phase timing experiment (scratch builds only): one wave of one mid-grid workgroup stamps s_memtime

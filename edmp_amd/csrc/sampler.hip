@@ -42,7 +42,7 @@ struct Sampler {
     int run_B = 0;          // batch of the run whose state sits in X (segmented runs)
     int condition = 1;      // pin X[:, :, 0] / X[:, :, -1] to start / goal (diffusion.py:305-307, 347-349)
     int cap = 0;            // elements
-    // whole-run hipGraph (EDMP_GRAPH=1): the enqueue of one denoise_loop call captured once and replayed while the
+    // whole-run hipGraph (edmp_sampler_set_graph): the enqueue of one denoise_loop call captured once and replayed while the
     // call's arguments stay the same (start/goal travel through `sg`, so they are not part of the key)
     struct GraphKey {
         const void* noise = nullptr;
@@ -56,7 +56,7 @@ struct Sampler {
         }
     } gkey;
     hipGraphExec_t gexec = nullptr;
-    int graph_on = -1;  // -1 = read EDMP_GRAPH on first use
+    int graph_on = 0;   // edmp_sampler_set_graph
     int graph_captures = 0, graph_replays = 0;
     double* qcoef = nullptr;  // [B][2] sqrt(a), sqrt(1 - a) of edmp_q_sample_dev
     int qcoef_cap = 0;
@@ -451,9 +451,6 @@ extern "C" int edmp_ctx_create(int device, edmp_ctx** out) {
     edmp_ctx* c = new edmp_ctx();
     c->device = device;
     EDMP_HIP_CHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    EDMP_HIP_CHECK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-    EDMP_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    EDMP_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     c->stream = c->own_stream;
     *out = c;
     return EDMP_OK;
@@ -477,12 +474,6 @@ extern "C" void edmp_ctx_destroy(edmp_ctx* ctx) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
-    if (ctx->side_stream) {
-        (void)hipStreamSynchronize(ctx->side_stream);
-        (void)hipStreamDestroy(ctx->side_stream);
-    }
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -838,10 +829,6 @@ static int denoise_loop(edmp_ctx* ctx, const double* noise_dev, bool use_rng, ui
     } else {
         EDMP_REQUIRE(s->X && s->run_B == B, "no run in progress for batch %d (call with init first)", B);
     }
-    if (s->graph_on < 0) {
-        const char* e = getenv("EDMP_GRAPH");
-        s->graph_on = (e && e[0] && e[0] != '0') ? 1 : 0;
-    }
     // a caller-supplied collective is not capturable; segments of a chunked run carry a fresh noise pointer each, so a
     // captured graph would never be replayed (capture + instantiate + destroy per chunk): they are enqueued directly
     const bool graph = allow_graph && s->graph_on == 1 && !ctx->prof.on && (!s->ar_fn || sampler_hook_is_native(s)) && loop_chains(ctx, B, guided) == 1;
@@ -880,7 +867,6 @@ static int denoise_loop(edmp_ctx* ctx, const double* noise_dev, bool use_rng, ui
         EDMP_HIP_CHECK(e);
         s->gkey = key;
         s->graph_captures++;
-        if (getenv("EDMP_GRAPH_DEBUG")) fprintf(stderr, "[edmp] captured run graph #%d (replays so far %d)\n", s->graph_captures, s->graph_replays);
         EDMP_HIP_CHECK(hipGraphLaunch(s->gexec, st));
         if (X_out_dev) EDMP_HIP_CHECK(hipMemcpyAsync(X_out_dev, s->X, n * sizeof(double), hipMemcpyDeviceToDevice, st));
     }

@@ -135,7 +135,6 @@ struct Op {
     int rc_bf3;   // OP_RCB / OP_WRS: 1 = runs on the bf16 matrix pipe with exact products (bf3.hip; bf3_select, frozen at build time)
     int wrs_kind; // OP_WRS: WK_DOWN / WK_UP
     int tb_off;   // GN: offset into the time-bias row, -1 if none
-    int branch;   // 0 = main stream; 1 = fork point (record before this op); 2 = runs on the side stream; 3 = join (wait) before this op
 
     double flops_nominal, flops_exec;  // per trajectory: every tap | MFMA work actually issued (padding taps skipped, Karatsuba forms)
     double flops_direct;               // per trajectory: the direct form with padding taps skipped (round-1 'executed' accounting)
@@ -164,7 +163,6 @@ struct UNet {
     double flops_nominal = 0, flops_exec = 0, flops_direct = 0;
     double flops_bf16 = 0, flops_f32_moved = 0;  // issued on the bf16 pipe | the fp32 work (direct form) those ops replace
     int layout = 0;  // layout id of the packed weight image (Packer::layout_id)
-    bool fuse_tail = true;  // EDMP_NO_FUSED_TAIL at build time
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -562,12 +560,10 @@ static int launch_gn(const GnP& p, hipStream_t s) {
 // Builder switches, read from the environment WHEN A MODEL IS BUILT (edmp_unet_load*) and frozen into its layer program:
 // two models built under different settings can live side by side in one process (A/B runs, the adversarial-weights test).
 // EDMP_NO_KARATSUBA=1: the L = 2 convolutions of the 512-channel levels in the direct form instead of the Karatsuba form
-// (3 instead of 4 matrix products; wide.hip WK_K5K2) - and, with it or with EDMP_NO_KARATSUBA4=1, the L = 4 convolutions of
-// the 256/512-channel levels (nested form, 9 instead of 14 products; WK_K5K4).  EDMP_NO_FUSED_TAIL=1: the step's tail stays
-// its own launch.
+// (3 instead of 4 matrix products; wide.hip WK_K5K2) and the L = 4 convolutions of the 256/512-channel levels (nested form, 9 instead
+// of 14 products; WK_K5K4).
 static bool karatsuba_l2() { return getenv("EDMP_NO_KARATSUBA") == nullptr; }
-static bool karatsuba_l4() { return getenv("EDMP_NO_KARATSUBA") == nullptr && getenv("EDMP_NO_KARATSUBA4") == nullptr; }
-static bool fuse_tail() { return !getenv("EDMP_NO_FUSED_TAIL"); }
+static bool karatsuba_l4() { return karatsuba_l2(); }
 static bool rcb_supported(int cout, int L, int c1, int c2) {
     const int cg = cout / 8;
     const bool shape = (cg == 64 && (L == 2 || L == 4)) || (cg == 32 && (L == 4 || L == 7)) || (cg == 16 && (L == 7 || L == 13));
@@ -699,29 +695,6 @@ static int level_sb(int variant) {
     const char* t = (e && strlen(e) == 4) ? e : kDefault;
     return t[variant - 1] == '2' ? 2 : 4;
 }
-// EDMP_LEVEL_STAGGER=<cycles>@<bit>[;<cycles>@<bit> ... for variants 1..4]: phase offset of the co-resident workgroups (LevelP::stagger_*),
-// read when a model is built (A/B runs)
-static void level_stagger(int variant, int* cycles, int* bit) {
-    static const char kDefault[] = "";
-    const char* e = getenv("EDMP_LEVEL_STAGGER");
-    const char* t = e ? e : kDefault;
-    *cycles = 0, *bit = 0;
-    int k = 1;
-    while (*t) {
-        int c = 0, b = 0;
-        if (sscanf(t, "%d@%d", &c, &b) < 1) break;
-        const char* semi = strchr(t, ';');
-        if (!semi) {  // one pair: every variant
-            if (k == 1) *cycles = c, *bit = b;
-            else if (k == variant) *cycles = c, *bit = b;
-            break;
-        }
-        if (k == variant) *cycles = c, *bit = b;
-        t = semi + 1;
-        ++k;
-        if (k == variant && !*t) break;
-    }
-}
 // EDMP_LEVEL_MERGE=<mask> (read at model-build time): bit 0 = the two down levels of the 32/64-channel resolutions (variants 1 + 2) as
 // ONE launch, level 1's k3s2 output handed to level 2 in LDS (level.hip: level2_kernel; two samples per workgroup); bit 1 = the two
 // last up levels (variants 3 + 4) likewise, the ConvTranspose output of the 64-channel level going into the first half of the last
@@ -839,7 +812,7 @@ struct Packer {
     bool dry = false;   // layout only: offsets and sizes are computed, nothing is written (loading a packed image)
     size_t total = 0;   // floats packed so far (== host.size() unless dry)
     // signature of the layout actually produced: every tensor's packing form and size, in order (FNV-1a).  The builder's
-    // run-time switches (EDMP_NO_FUSED, EDMP_NO_RESFOLD, EDMP_NO_LEVEL, EDMP_NO_KARATSUBA[4], EDMP_SIDE_STREAM) move
+    // run-time switches (EDMP_NO_FUSED, EDMP_NO_RESFOLD, EDMP_NO_LEVEL, EDMP_NO_KARATSUBA, EDMP_BF16X3, EDMP_MS16, EDMP_LEVEL_MERGE, EDMP_LEVEL_SB) move
     // tensors or change their fragment order, several of them without changing the total: the signature is what makes an
     // image written under one setting unloadable under another
     uint64_t sig = 1469598103934665603ull;
@@ -1011,7 +984,6 @@ struct POp {
     size_t gamma, beta;
     int tb_off;
     double fn, fe, fd;  // FLOPs per trajectory: nominal | issued | direct form without padding taps (0: same as fe)
-    int branch;
     size_t br;  // bias of a residual 1x1 conv folded into an OP_RCB
     int blk;
     int res_out;  // OP_RCB: buffer receiving the folded residual 1x1 conv (-1: none)
@@ -1024,13 +996,12 @@ struct POp {
 // the builder's run-time switches, read ONCE per model build and frozen into its plan (two models built under different settings
 // coexist in one process: A/B runs, the adversarial-weights test)
 struct BuildSwitches {
-    bool fused, side, resfold, level;
+    bool fused, resfold, level;
     static BuildSwitches read() {
         BuildSwitches s;
         s.fused = getenv("EDMP_NO_FUSED") == nullptr;
-        s.side = getenv("EDMP_SIDE_STREAM") != nullptr;  // measured slower (event sync > overlap gain): opt-in
         s.resfold = getenv("EDMP_NO_RESFOLD") == nullptr;
-        s.level = s.fused && getenv("EDMP_NO_LEVEL") == nullptr && !s.side;
+        s.level = s.fused && getenv("EDMP_NO_LEVEL") == nullptr;
         return s;
     }
 };
@@ -1176,7 +1147,7 @@ struct LayerPlan {
             const int cin_store = x.C + (x2 ? x2->C : 0);
             // conv1 (a residual 1x1 conv folded into the wide fused kernel is packed right behind it, as tap index 5)
             const bool wide = sw.fused && rcb_supported(r.cout, x.L, x.C, x2 ? x2->C : 0);
-            const bool fold_res = wide && r.has_res && sw.resfold && !sw.side;
+            const bool fold_res = wide && r.has_res && sw.resfold;
             // the position-tile kernel reads its weights as an MFMA fragment stream (wide.hip); the generic conv as [tap][Cout][Cin]
             size_t w1 = wide ? pk.conv_frag(params + r.cb[0].w.off, fold_res ? params + r.rw.off : nullptr, r.cout, r.cin, cin_store, x.L)
                              : pk.conv(params + r.cb[0].w.off, r.cout, r.cin, 5, cin_store);
@@ -1203,19 +1174,16 @@ struct LayerPlan {
                     rr_buf = c1.res_out;
                     res_buf = c1.res_out;
                 } else if (r.has_res) {
-                    // the residual 1x1 conv only depends on the block input: it runs concurrently with conv1 on the side stream
+                    // (EDMP_NO_RESFOLD: the residual 1x1 conv as its own launch)
                     size_t wr = pk.conv(params + r.rw.off, r.cout, r.cin, 1, cin_store);
                     size_t br = pk.vec(params + r.rb.off, r.cout);
-                    if (sw.side) pops.back().branch = 1;
                     TH rr = emit_conv(x, x2, r.cin, wr, br, r.cout, 1, 1, 0, false, x.L);
-                    if (sw.side) pops.back().branch = 2;
                     rr_buf = rr.buf;
                     res_buf = rr.buf;
                 } else {
                     res_buf = x2 ? -2 : x.buf;
                 }
                 TH out = emit_fused(h, nullptr, r.cout, r.cout, w2, b2, g2, be2, res_buf, -1);
-                if (sw.side && r.has_res) pops.back().branch = 3;
                 pool.put(h.buf);
                 if (rr_buf >= 0) pool.put(rr_buf);
                 return out;
@@ -1430,7 +1398,6 @@ static void resolve_program(UNet* u, const LayerPlan& pl) {
         Op op{};
         op.kind = o.kind;
         op.tb_off = -1;
-        op.branch = o.branch;
         if (o.kind == OP_CONV) {
             ConvP& c = op.cv;
             c.src1 = u->bufs[o.src1];
@@ -1473,7 +1440,6 @@ static void resolve_program(UNet* u, const LayerPlan& pl) {
             op.lv_variant = o.lv_variant;
             op.lv_merge = o.lv_merge;
             op.lv_sb = level_sb(o.lv_variant);
-            level_stagger(o.lv_variant, &c.stagger_cycles, &c.stagger_bit);
             op.lv_tb1 = o.lv_tb1;
             op.lv_tb2 = o.lv_tb2;
             op.flops_nominal = o.fn;
@@ -1590,7 +1556,6 @@ static int unet_build(edmp_ctx* ctx, const edmp_unet_desc* desc, const float* pa
     UNet* u = guard.get();
     u->desc = *desc;
     u->max_batch = max_batch;
-    u->fuse_tail = fuse_tail();
     LayerPlan pl(desc, params, packed != nullptr);
     if (int rc = pl.plan()) return rc;
     u->tb_stride = pl.tb_cursor;
@@ -1706,7 +1671,7 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
     auto coff = [&](auto* q) { return q ? q + unet_chain_offset(u, q, r0) : q; };
     // the tail of the reverse step runs inside the last level's launch when that level is the program's last op (LV_UP_FINAL, 32 channels)
     auto fuse_step_tail = [&](LevelP& p, const Op& o, int index, bool out_is_head_input) {
-        if (tail && tail_done && o.lv_variant == 4 && index + 1 == (int)u->prog.size() && u->head_cin == 32 && tail->N == u->desc.horizon && tail->C <= 8 && out_is_head_input && u->fuse_tail) {
+        if (tail && tail_done && o.lv_variant == 4 && index + 1 == (int)u->prog.size() && u->head_cin == 32 && tail->N == u->desc.horizon && tail->C <= 8 && out_is_head_input) {
             p.tail = *tail;
             p.tail.on = 1;
             p.tail.w = u->head_w;
@@ -1719,15 +1684,6 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
         ++op_index;
         if (op_index == skip_index) continue;  // the second level of a merged pair: ran inside the previous launch
         hipStream_t s = main_stream;
-        EDMP_REQUIRE(!(run_stream && op.branch), "the side-stream build of the layer program (EDMP_SIDE_STREAM) cannot run as row chains");
-        if (op.branch == 1) {
-            EDMP_HIP_CHECK(hipEventRecord(ctx->ev_fork, main_stream));
-        } else if (op.branch == 2) {
-            s = ctx->side_stream;
-            EDMP_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_fork, 0));
-        } else if (op.branch == 3) {
-            EDMP_HIP_CHECK(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
-        }
         Prof::Pend ev{nullptr, nullptr, op_index};
         const bool timed = pf.on == 1 && op.kind != OP_GN;
         if (timed) {
@@ -1792,7 +1748,6 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
             EDMP_HIP_CHECK(hipEventRecord(ev.b, s));
             pf.pending.push_back(ev);
         }
-        if (op.kind == OP_CONV && op.branch == 2) EDMP_HIP_CHECK(hipEventRecord(ctx->ev_join, s));
     }
     if (pf.on == 2) {
         EDMP_HIP_CHECK(hipEventRecord(whole.b, main_stream));

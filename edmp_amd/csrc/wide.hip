@@ -768,14 +768,11 @@ inline void pack_fragments_k4(const float* w_tco_ci, int cout, int cin, bool res
 
 // How the 8 XCDs split a (channel groups x sample tiles) grid: gx of them across the groups, 8 / gx across the tiles.
 // HBM fetches = weights x (8 / gx) + activations x gx (each L2 fetches what its workgroups touch); 0 = grid does not divide.
-// EDMP_XCD_SPLIT=<gx> forces one split (ablation).
 inline int xcd_split(int ng, int nt, double w_elems, double a_elems) {
-    static const int forced = [] { const char* e = getenv("EDMP_XCD_SPLIT"); return e ? atoi(e) : -1; }();
     int best = 0;
     double cost = 0.0;
     for (int gx = 1; gx <= 8; gx *= 2) {
         if (ng % gx || nt % (8 / gx)) continue;
-        if (forced >= 0 && gx != forced) continue;
         const double c = w_elems * (8 / gx) + a_elems * gx;
         if (!best || c < cost) best = gx, cost = c;
     }

@@ -46,8 +46,8 @@ class Diffusion:
         self.ctx = get_context(device)
         self.device = self.ctx.device
         self.ctx.ensure_sampler(self.T, self.variance_thresh)
-        # row chains of one batch in the device-resident loop (denoise_guided(chains=...)); EDMP_CHAINS sets the default
-        self.chains = int(os.environ.get("EDMP_CHAINS", "1"))
+        # row chains of one batch in the device-resident loop (denoise_guided(chains=...)): 1 unless the caller sets it
+        self.chains = 1
         self.beta = np.zeros(self.T)
         self.alpha = np.zeros(self.T)
         self.alpha_bar = np.zeros(self.T)

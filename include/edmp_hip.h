@@ -191,7 +191,7 @@ int edmp_rng_normal_dev(edmp_ctx* ctx, uint64_t seed, int step_index, int B, int
 /* Replay mode of the device-resident loop: on = 1 captures the stream work of one edmp_denoise_guided*_dev call
  * (255 reverse steps, ~16k kernel nodes) into a hipGraph the first time and replays it while the call's arguments,
  * scene, rows and weights stay the same (start/goal are read from a device buffer and may change freely).  Results are
- * bit-identical to the eager enqueue.  Off by default (also switched on by the environment variable EDMP_GRAPH=1):
+ * bit-identical to the eager enqueue.  Off by default:
  * measured neutral on MI355X at B = 4..1024 - the loop is bound by kernel execution, not by launch. */
 int edmp_sampler_set_graph(edmp_ctx* ctx, int on);
 
@@ -202,7 +202,7 @@ int edmp_sampler_set_graph(edmp_ctx* ctx, int on);
  * (lib/guide.py:629): every chain writes its rows' partial sums, waits (HIP events) until all chains have, and normalises by the
  * total formed in the single-chain summation order, so results are BIT-IDENTICAL to chains = 1 (Q7's NaN rule included).
  * Ignored (= 1) while an all-reduce hook or profiling brackets are active.  chains > 1 takes precedence over hipGraph replay
- * (edmp_sampler_set_graph / EDMP_GRAPH=1): such a call is enqueued eagerly, nothing is captured.  1 <= chains <= 16; default 1. */
+ * (edmp_sampler_set_graph): such a call is enqueued eagerly, nothing is captured.  1 <= chains <= 16; default 1. */
 int edmp_sampler_set_chains(edmp_ctx* ctx, int chains);
 
 /* ---- training-side forward process --------------------------------------------------------- */
