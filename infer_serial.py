@@ -46,7 +46,7 @@ def _ranks(device):
 
 
 class _NoiseFeeder:
-    """Scenes in flight: every scene's (T+1, B, C, N) noise stream, drawn IN SCENE ORDER from the global NumPy RandomState (so each
+    """Every scene's (T+1, B, C, N) noise stream, drawn IN SCENE ORDER from the global NumPy RandomState (so each
     scene sees the numbers the serial loop would give it) by ONE background thread into page-locked whole-scene buffers, ahead of the
     scene that consumes it; the planning threads upload their buffer by DMA.  Drawing on the calling thread instead serialised the
     loop on the host: 0.16 s of draws + a pageable 734 MB upload per 1024-row scene made two scenes in flight SLOWER than the serial
@@ -67,29 +67,46 @@ class _NoiseFeeder:
             self.free.put(b)
         nthr = nprng.draw_threads()
 
+        from edmp_amd.diffusion import PinnedNoiseStream
+
+        per_step = int(np.prod(shape[1:]))
+        pieces, left, kk, first = [], int(shape[0]) - 1, 1, True  # (X_T + 1 step), 2, 4, 8, 16, 16, ... steps: the sampler's own chunk plan
+        while left > 0:
+            st = min(kk, 16, left)
+            pieces.append((st + (1 if first else 0)) * per_step)
+            left, kk, first = left - st, kk * 2, False
+
         def work():
+            stream = None
             try:
                 for _ in range(n_scenes):
                     b = self.free.get()
                     if b is None:
                         return
-                    nprng.standard_normal((n,), nthreads=nthr, out=b.numpy())
-                    self.ready.put(b)
-            except BaseException as exc:  # surfaced by next()
+                    stream = PinnedNoiseStream(b.view(self.shape))
+                    self.ready.put(stream)  # handed out at once: the consumer uploads each chunk as soon as it is drawn
+                    flat, off = b.numpy(), 0
+                    for m in pieces:  # piecewise draws continue the legacy stream exactly (the cached second gauss value travels in the state)
+                        nprng.standard_normal((m,), nthreads=nthr, out=flat[off:off + m])
+                        off += m
+                        stream.publish(off)
+            except BaseException as exc:  # surfaced by next() / by the consumer's wait
+                if stream is not None:
+                    stream.publish(stream.drawn, error=exc)
                 self.ready.put(exc)
 
         self.thread = threading.Thread(target=work, name="edmp-scene-noise", daemon=True)
         self.thread.start()
 
     def next(self):
-        """the next scene's stream (scene order): a pinned (T+1, B, C, N) f64 tensor; blocks until it is drawn"""
+        """the next scene's stream (scene order): a PinnedNoiseStream over a pinned (T+1, B, C, N) f64 tensor, possibly still being drawn"""
         b = self.ready.get()
         if isinstance(b, BaseException):
             raise b
-        return b.view(self.shape)
+        return b
 
-    def recycle(self, t):
-        self.free.put(t.view(-1))
+    def recycle(self, stream):
+        self.free.put(stream.tensor.view(-1))
 
     def close(self):
         self.free.put(None)
@@ -123,7 +140,9 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=
     that many scenes concurrently on one GPU, each on its own context / stream / host thread: every launch of the sampler is one
     wave of 256 workgroups, a second independent scene fills its dispatch gaps and kernel tails (+7-9 % throughput measured,
     bench.py: two_scenes_in_flight).  Per-scene results are identical to the serial loop's: scenes are prepared in order on the
-    calling thread and each scene's noise is drawn there from the global NumPy RandomState, in the order the serial loop draws it."""
+    calling thread and each scene's noise is drawn - by ONE background feeder thread, a whole scene ahead, serial loop included - from the
+    global NumPy RandomState in scene order.  While a run is in progress nothing else may draw from (or seed) the global RandomState: the
+    feeder reads and advances it from its own thread (np.random.get_state / set_state are not atomic)."""
     from concurrent.futures import ThreadPoolExecutor
 
     from edmp_amd.runtime import get_context, lane_context
@@ -169,11 +188,11 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=
         diffuser, denoiser = lanes[lane]
         tm = dict(meta.pop("timings"))
         pinned = None
-        if noise is not None:  # scenes in flight: this scene's stream, drawn ahead by the feeder; one DMA, then the buffer goes back
+        if noise is not None:  # this scene's stream, drawn ahead by the feeder into page-locked memory: uploaded in chunks beside the loop
             t_w = time.time()
-            pinned = noise if isinstance(noise, torch.Tensor) else noise.result()
+            pinned = noise.result() if hasattr(noise, "result") else noise
             tm["noise_wait_s"] = time.time() - t_w
-            noise = diffuser.ctx.to_dev(pinned, torch.float64)
+            noise = pinned
         ta = time.time()
         trajectories = diffuser.denoise_guided(model=denoiser, guide=guide, batch_size=total_batch_size, traj_len=traj_len,
                                                num_channels=num_channels, condition=True, benchmarking=True, start=start_joints,
@@ -221,7 +240,9 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=
             if i % world == rank:
                 mine.append((i, scene_type, scene_num))
             i += 1
-    feeder = _NoiseFeeder(base, len(mine), (T + 1, total_batch_size, num_channels, traj_len), k + 1) if (k > 1 and mine) else None
+    # the noise of EVERY scene comes from the feeder thread, one whole scene ahead (round 6: the serial loop too - drawing chunk by chunk
+    # beside the GPU had no margin left once a reverse step took 0.92 ms: a slower host capped the scene loop, BENCH_r05 0.947 x value)
+    feeder = _NoiseFeeder(base, len(mine), (T + 1, total_batch_size, num_channels, traj_len), k + 1) if mine else None
     run.last_setup_s = time.time() - t_enter  # config, dataset, model load / upload: per run, not per scene
     try:
         with ThreadPoolExecutor(max_workers=k) as pool:
@@ -243,13 +264,13 @@ def run(cfg_path, dataset=None, max_scenes=None, verbose=True, scenes_in_flight=
                 goal_joints = all_ik_goals[indices][volumes[indices] < np.min(volumes) + 0.0008]
                 goal_joints = goal_joints[np.argmin(np.linalg.norm(start_joints - goal_joints, axis=1))]
                 t2 = time.time()
-                # serial loop: the sampler draws from the global RandomState while the GPU works (noise=None); several scenes in
-                # flight: the feeder thread draws every scene's whole stream in scene order, so every scene sees the numbers it would
-                # see serially.  (pool.submit hands the scenes to the lanes in order, the feeder hands the streams out in the same order)
+                # the feeder thread draws every scene's whole stream in scene order from the global RandomState, so every scene sees the
+                # numbers the reference's loop would give it (nothing else may draw from the global state while a run is in progress).
+                # (pool.submit hands the scenes to the lanes in order, the feeder hands the streams out in the same order)
                 # where a scene's "Planning Time" (infer_serial.py:108-157: guide construction + IK filter + sampling + best pick) goes
                 meta = dict(scene_type=scene_type, scene_num=scene_num, timings=dict(guide_ctor_s=t1 - t0, ik_filter_s=t2 - t1))
                 if k == 1:
-                    collect(plan(lane, guide, start_joints, goal_joints, None, meta, t0))  # serial: the reference's order of events
+                    collect(plan(lane, guide, start_joints, goal_joints, feeder.next(), meta, t0))  # serial: the reference's order of events
                 else:
                     pending.append(pool.submit(plan, lane, guide, start_joints, goal_joints, feeder.next(), meta, t0))
             while pending:
