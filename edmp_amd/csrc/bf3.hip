@@ -231,10 +231,6 @@ __global__ __launch_bounds__(512) void bf3_conv_kernel(const float* a_src1, cons
                 f32x2_t lo2 = {x[k].x, x[k].y}, hi2 = {x[k].z, x[k].w};
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
-#ifdef EDMP_BF3_ABL_NOSPLIT  // ablation (tools only): the three planes written without the split's VALU work
-                    *reinterpret_cast<u32x2_t*>(st + a_l[k] + m * PLANE) = u32x2_t{__builtin_bit_cast(unsigned, x[k].x), __builtin_bit_cast(unsigned, x[k].z)};
-                    continue;
-#endif
                     const bf16x2_t c01 = __builtin_convertvector(lo2, bf16x2_t), c23 = __builtin_convertvector(hi2, bf16x2_t);
                     *reinterpret_cast<u32x2_t*>(st + a_l[k] + m * PLANE) = u32x2_t{__builtin_bit_cast(unsigned, c01), __builtin_bit_cast(unsigned, c23)};
                     if (m < 2) {
@@ -325,9 +321,6 @@ __global__ __launch_bounds__(512) void bf3_conv_kernel(const float* a_src1, cons
                 }
             });
             // refill with the next chunk's components (the last chunk re-reads its own: harmless)
-#ifdef EDMP_BF3_ABL_NOW  // ablation (tools only): the weight registers are never refilled
-            if (kgn < 0)
-#endif
             if constexpr (ph == 0) {
                 load_w(kgn, std::integral_constant<int, 2>{});
                 load_w(kgn, std::integral_constant<int, 1>{});
@@ -366,16 +359,12 @@ __global__ __launch_bounds__(512) void bf3_conv_kernel(const float* a_src1, cons
     } else {
         // step c: split + commit chunk c + 1 (fetched a step ago or in the prologue) into the other stage, fetch chunk c + 3 into its registers
         for (int c = 0; c < nK; c += 2) {
-#ifndef EDMP_BF3_ABL_NOSTAGE  // ablation (tools only): the staging waves only pass the barriers
             if (c + 1 < nK) commit(stg + STAGE, xb);
             if (c + 3 < nK) fetch(c + 3, xb);
-#endif
             __syncthreads();
             if (c + 1 < nK) {
-#ifndef EDMP_BF3_ABL_NOSTAGE
                 if (c + 2 < nK) commit(stg, xa);
                 if (c + 4 < nK) fetch(c + 4, xa);
-#endif
                 __syncthreads();
             }
         }
