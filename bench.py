@@ -84,8 +84,6 @@ def main():
     ap.add_argument("--no-two-scenes", action="store_true", help="skip the informative two-scenes-in-flight measurement")
     ap.add_argument("--no-native-leg", action="store_true", help="skip the A/B leg with every conv on the fp32-MFMA kernels (value_native_f32)")
     ap.add_argument("--no-problem-set", action="store_true", help="skip the informative problem-set measurement (16 distinct scenes through infer_serial.run)")
-    ap.add_argument("--chains", type=int, default=1,
-                    help="run the one batch as this many row-sharded chains on separate HIP streams (edmp_sampler_set_chains; bit-identical results)")
     args = ap.parse_args()
 
     backend = os.environ.get("EDMP_DIST_BACKEND", "nccl")  # "gloo" lets N ranks share one GPU (single-GPU test boxes)
@@ -150,7 +148,6 @@ def main():
     net = TemporalUNet(None, C, 32, dev, dims=FULL_DIMS, seed=1, max_batch=B)
     guide = IntersectionVolumeGuide(scene, dev, cfgs, B)
     dif = Diffusion(T, dev)
-    dif.chains = max(1, args.chains)
     ctx = dif.ctx
     noise_host = np.random.RandomState(1234 + rank).standard_normal((T + 1, B, C, N))
     noise = ctx.to_dev(noise_host, torch.float64)
@@ -270,7 +267,6 @@ def main():
             "config": {
                 "workload": f"denoise_guided T={T} N={N} batch={B}/GPU, {len(guides)}-guide ensemble {guides}, {args.obstacles}-cuboid synthetic scene, full TemporalUNet (29.9M params, random init), f64 state / f32 denoiser+guide",
                 "global_batch": world * B,
-                "row_chains": dif.chains,  # chains of the ONE batch on separate streams (bit-identical to 1)
                 "parallelism": (f"one logical batch of {world * B} rows row-sharded x{world}: RCCL all-reduce of sum(g^2) per guided step inside the device loop + end-of-sampling gather"
                                 if logical else (f"row-sharded replicas x{world}, end-of-sampling RCCL gather" if world > 1 else "single GPU")),
             },

@@ -72,7 +72,6 @@ SIGNATURES = {
     "edmp_denoise_guided_rng_dev": (_i, [_vp, C.c_uint64, _i, _pd, _pd, _i, _i, _i, _vp]),
     "edmp_rng_normal_dev": (_i, [_vp, C.c_uint64, _i, _i, _i, _i, _vp]),
     "edmp_sampler_set_graph": (_i, [_vp, _i]),
-    "edmp_sampler_set_chains": (_i, [_vp, _i]),
     "edmp_q_sample_dev": (_i, [_vp, _vp, _vp, _pi32, _i, _i, _i, _i, _i, _vp, _vp]),
     "edmp_unet_packed_size": (C.c_int64, [_vp, C.POINTER(C.c_int)]),
     "edmp_unet_read_packed": (_i, [_vp, _pf, C.c_int64]),

@@ -142,7 +142,6 @@ struct GuideArgs {
     const float* startgoal;  // [14] f32
     float* out;              // volumes / raw gradient / row sums
     double* rowsq;           // GM_GRAD: per-row sum g^2
-    int row0 = 0;            // first row of this launch (row chains of one batch, sampler.hip); rows [row0, n) are processed
 };
 
 struct Vec3 {
@@ -188,9 +187,9 @@ __global__ __launch_bounds__(256, (SPLIT == 4 ? 4 : 1)) void guide_kernel(GuideA
     __shared__ float s_g[SPLIT == 4 ? 3 : 1][SPLIT == 4 ? 7 : 1][64];  // partial gradients of waves 1..3
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = (SPLIT == 4) ? a.row0 + blockIdx.x : a.row0 + blockIdx.x * 4 + wv;
+    const int r = (SPLIT == 4) ? blockIdx.x : blockIdx.x * 4 + wv;
     const bool row_ok = r < a.n;
-    const int rr = row_ok ? r : a.row0;
+    const int rr = row_ok ? r : 0;
     const int L = a.L;
     const int no = a.no;
     // obstacle AABBs of this row's class at step t -> LDS slice of this wave (SPLIT = 4: one table for the row's four waves)
@@ -523,7 +522,7 @@ static int ensure_scratch(edmp_ctx* ctx, Guide* g, int B, int L, bool* realloc =
     g->vol_rows = nullptr;
     int nb = std::max(B, g->scratch_B), nl = std::max(L, g->scratch_L);
     if (int rc = ctx_alloc(ctx, (void**)&g->graw, (size_t)nb * 7 * nl * sizeof(float))) return rc;
-    if (int rc = ctx_alloc(ctx, (void**)&g->rowsq, (size_t)2 * nb * sizeof(double))) return rc;  // two buffers: row chains alternate between them per guided step
+    if (int rc = ctx_alloc(ctx, (void**)&g->rowsq, (size_t)nb * sizeof(double))) return rc;
     if (int rc = ctx_alloc(ctx, (void**)&g->vol_rows, (size_t)nb * sizeof(float))) return rc;
     g->scratch_B = nb;
     g->scratch_L = nl;
@@ -546,7 +545,7 @@ static int upload_startgoal(edmp_ctx* ctx, const float* start, const float* goal
 
 template <int MODE, class TIn>
 static int launch_guide(edmp_ctx* ctx, const TIn* joints, int ldw, int off, int n, int L, int t, int use_row_class, int do_clip, float* out,
-                        double* rowsq, int row0 = 0, hipStream_t run_stream = nullptr) {
+                        double* rowsq) {
     Guide* g = ctx->guide;
     GuideArgs<TIn> a;
     a.joints = joints;
@@ -565,13 +564,12 @@ static int launch_guide(edmp_ctx* ctx, const TIn* joints, int ldw, int off, int 
     a.startgoal = g->startgoal;
     a.out = out;
     a.rowsq = rowsq;
-    a.row0 = row0;
-    hipStream_t st = run_stream ? run_stream : ctx->stream;
+    hipStream_t st = ctx->stream;
     if constexpr (MODE == GM_GRAD) {
         // the gradient: four waves per row, one per link group (round 5: 44 -> 28 us per launch against one wave per row)
-        hipLaunchKernelGGL((guide_kernel<MODE, TIn, 4>), dim3(n - row0), dim3(256), 0, st, a, g->rc);
+        hipLaunchKernelGGL((guide_kernel<MODE, TIn, 4>), dim3(n), dim3(256), 0, st, a, g->rc);
     } else {
-        hipLaunchKernelGGL((guide_kernel<MODE, TIn, 1>), dim3((n - row0 + 3) / 4), dim3(256), 0, st, a, g->rc);
+        hipLaunchKernelGGL((guide_kernel<MODE, TIn, 1>), dim3((n + 3) / 4), dim3(256), 0, st, a, g->rc);
     }
     EDMP_HIP_CHECK(hipGetLastError());
     return EDMP_OK;
@@ -587,26 +585,20 @@ int guide_prepare(edmp_ctx* ctx, int B, int L) {  // allocate the step scratch u
     return rc;
 }
 // reduce = false: the caller's update kernel sums the per-row partials itself (device-resident loop without a hook)
-// Rows [r0, r1) of the B-row batch whose state is X_dev (the whole batch: r0 = 0, r1 = B) on `run_stream` (null: the context's);
-// `buf` selects one of the two per-row sum buffers (row chains alternate per guided step, see sampler.hip).  The scratch must
-// already be large enough when chains run concurrently (guide_prepare): nothing is (re)allocated under another chain's feet.
-int guide_raw_gradient_from_X(edmp_ctx* ctx, const double* X_dev, int B, int N, int t, bool reduce, int r0, int r1, int buf, hipStream_t run_stream) {
+int guide_raw_gradient_from_X(edmp_ctx* ctx, const double* X_dev, int B, int N, int t, bool reduce) {
     Guide* g = ctx->guide;
     EDMP_REQUIRE(g && g->aabb && g->row_class, "scene/rows not set");
     EDMP_REQUIRE(B == g->B, "batch %d != rows set (%d)", B, g->B);
     EDMP_REQUIRE(t >= 0 && t <= g->T, "t out of range");
-    EDMP_REQUIRE(0 <= r0 && r0 < r1 && r1 <= B && (buf == 0 || buf == 1), "bad row range %d..%d of %d", r0, r1, B);
-    EDMP_REQUIRE(!(reduce && (r0 != 0 || r1 != B)), "the stand-alone reduction runs over the whole batch");
     int rc = ensure_scratch(ctx, g, B, N - 2);
     if (rc) return rc;
-    hipStream_t st = run_stream ? run_stream : ctx->stream;
-    rc = launch_guide<GM_GRAD, double>(ctx, X_dev, N, 1, r1, N - 2, t, 1, 1, g->graw, g->rowsq + (size_t)buf * g->scratch_B, r0, st);
+    rc = launch_guide<GM_GRAD, double>(ctx, X_dev, N, 1, B, N - 2, t, 1, 1, g->graw, g->rowsq);
     if (rc) return rc;
-    if (reduce) hipLaunchKernelGGL(reduce_rowsq_kernel, dim3(1), dim3(256), 0, st, g->rowsq + (size_t)buf * g->scratch_B, B, g->sumsq);
+    if (reduce) hipLaunchKernelGGL(reduce_rowsq_kernel, dim3(1), dim3(256), 0, ctx->stream, g->rowsq, B, g->sumsq);
     EDMP_HIP_CHECK(hipGetLastError());
     return EDMP_OK;
 }
-const double* guide_rowsq(edmp_ctx* ctx, int buf) { return ctx->guide->rowsq + (size_t)buf * ctx->guide->scratch_B; }
+const double* guide_rowsq(edmp_ctx* ctx) { return ctx->guide->rowsq; }
 int guide_set_startgoal(edmp_ctx* ctx, const double* start, const double* goal) {
     float s[7], gl[7];
     for (int i = 0; i < 7; ++i) {

@@ -563,7 +563,7 @@ __device__ __forceinline__ void level_body(const LevelP& p, float* lds, float* o
                         for (int q = 0; q < C / 4; ++q) hv[q] = *reinterpret_cast<const float4*>(TY + tid * RSC + 4 * q);
                         const TailP& tl = p.tail;
                         const int b = b0 + tail_sm, pos = tail_pos, i = b * LOUT + pos;
-#define EDMP_TAIL(FIN, RN) head_psample_item<FIN, RN, C>(hv, tail_x, tail_z, i, b, pos, TW, TW + 8 * C, tl.X, nullptr, tl.xin, tl.sg, LOUT, tl.C, tl.c1, tl.sqrt_alpha, tl.beta, tl.zero_row0, tl.seed, tl.rng_step, tl.cond, tl.elem0)
+#define EDMP_TAIL(FIN, RN) head_psample_item<FIN, RN, C>(hv, tail_x, tail_z, i, b, pos, TW, TW + 8 * C, tl.X, nullptr, tl.xin, tl.sg, LOUT, tl.C, tl.c1, tl.sqrt_alpha, tl.beta, tl.zero_row0, tl.seed, tl.rng_step, tl.cond)
                         if (tl.finish) {
                             if (tl.rng) EDMP_TAIL(true, true);
                             else EDMP_TAIL(true, false);

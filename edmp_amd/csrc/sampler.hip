@@ -21,10 +21,9 @@ void set_error(const char* fmt, ...) {
 
 // unet.hip / guide.hip
 int unet_forward_impl(edmp_ctx* ctx, const float* x_dev, int B, int t, float* eps_dev);
-int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_done, int r0, hipStream_t run_stream);
-int guide_raw_gradient_from_X(edmp_ctx* ctx, const double* X_dev, int B, int N, int t, bool reduce, int r0, int r1, int buf, hipStream_t run_stream);
-const double* guide_rowsq(edmp_ctx* ctx, int buf);
-size_t unet_chain_offset(const UNet* u, const float* p, int r0);
+int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_done);
+int guide_raw_gradient_from_X(edmp_ctx* ctx, const double* X_dev, int B, int N, int t, bool reduce);
+const double* guide_rowsq(edmp_ctx* ctx);
 int guide_set_startgoal(edmp_ctx* ctx, const double* start, const double* goal);
 int guide_prepare(edmp_ctx* ctx, int B, int L);
 const float* guide_graw(edmp_ctx* ctx);
@@ -66,25 +65,6 @@ struct Sampler {
     void* ar_user = nullptr;
     struct RcclHook* rccl = nullptr;              // rccl_hook.hip: the native hook's communicator, when that hook is installed
     uint64_t ar_calls = 0, ar_ns = 0, ar_max_ns = 0;  // host time spent inside the hook (edmp_sampler_allreduce_stats)
-    // Row chains of ONE batch (edmp_sampler_set_chains): the device-resident loop runs the batch as `chains` contiguous row
-    // ranges, each on its own stream.  Rows only meet in the whole-batch sum(g^2) of a guided step (lib/guide.py:629): every
-    // chain's guide kernel writes its rows' partial sums into the step's buffer (two buffers, alternating per guided step, so a
-    // fast chain never overwrites what a slow chain's update still reads), records an event, waits for the other chains'
-    // events, and its update kernel then sums ALL rows' partials in the single-chain order - results are bit-identical to
-    // chains = 1, Q7's NaN rule included.  Chain 0 runs on the context's stream.
-    int chains = 1;
-    std::vector<hipStream_t> cstream;          // [chains - 1]
-    std::vector<hipEvent_t> ev_grad[2];        // [buffer][chain]: the chain's gradient rows + partial sums of this guided step are written
-    std::vector<hipEvent_t> ev_done;           // [chain]: end of the chain's segment
-    hipEvent_t ev_fork = nullptr;
-};
-
-// one chain's share of the batch
-struct Span {
-    int r0 = 0, n = 0;          // rows [r0, r0 + n)
-    hipStream_t st = nullptr;
-    int B = 0;                  // rows of the whole batch
-    bool whole() const { return r0 == 0 && n == B; }
 };
 
 void sampler_rccl_destroy(Sampler* s);            // rccl_hook.hip
@@ -96,14 +76,6 @@ void sampler_destroy(Sampler* s) {
     for (void* p : {(void*)s->X, (void*)s->sg, (void*)s->qcoef})
         if (p) (void)hipFree(p);
     if (s->gexec) (void)hipGraphExecDestroy(s->gexec);
-    for (hipStream_t st : s->cstream) {
-        (void)hipStreamSynchronize(st);
-        (void)hipStreamDestroy(st);
-    }
-    for (auto& v : s->ev_grad)
-        for (hipEvent_t e : v) (void)hipEventDestroy(e);
-    for (hipEvent_t e : s->ev_done) (void)hipEventDestroy(e);
-    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     delete s;
 }
 
@@ -122,15 +94,14 @@ __global__ void psample_kernel(double* __restrict__ X, const float* __restrict__
 // of reduce_rowsq_kernel (bit-identical) - one launch less per guided step of the device-resident loop
 __global__ __launch_bounds__(256) void update_kernel(double* __restrict__ X, const float* __restrict__ graw, const double* __restrict__ sumsq,
                               const double* __restrict__ rowsq, const double* __restrict__ grad_norm, const double* __restrict__ sched, int sched_T, int t, int B, int C, int N,
-                              const double* __restrict__ sg, int guided, double* __restrict__ grad_out, float* __restrict__ xin, int cond, int i0, int i1) {
-    // elements [i0, i1) of the (B, C, N) state: the whole batch, or one row chain's share - the sum below always runs over ALL B rows
+                              const double* __restrict__ sg, int guided, double* __restrict__ grad_out, float* __restrict__ xin, int cond, int n) {
     __shared__ double sm[256];
     double total = 0.0;
     if (guided) total = rowsq ? block_sum_rowsq(rowsq, B, sm) : sumsq[0];
     // (one element per thread: a grid-stride variant with 256 blocks - the redundant reduction paid 256 instead of 1344 times - was
     // measured SLOWER, 11.6 vs 7.9 us: five dependent f64 round trips per thread at one wave per SIMD; round 5)
-    const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= i1) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
     const int l = i % N;
     const int c = (i / N) % C;
     const int b = i / (N * C);
@@ -224,8 +195,7 @@ template <bool FINISH, bool RNG, int CIN>
 __global__ __launch_bounds__(256) void head_psample_kernel(const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ bias,
                                                            double* __restrict__ X, const double* __restrict__ z, float* __restrict__ eps_out,
                                                            float* __restrict__ xin, const double* __restrict__ sg, int B, int N, int Cin, int C,
-                                                           double c1, double sqrt_alpha, double beta, int zero_row0, uint64_t seed, int rng_step, int cond, unsigned elem0) {
-    // (row chains: h / X / z / xin point at the chain's first row, B = its rows, elem0 = that row's element index in the batch)
+                                                           double c1, double sqrt_alpha, double beta, int zero_row0, uint64_t seed, int rng_step, int cond) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if constexpr (CIN > 0) {  // compile-time width: all input loads are issued back to back; the shared tail does the rest
         // the head's weights through LDS (224 wave-uniform scalar loads in a row serialise on the scalar cache)
@@ -243,7 +213,7 @@ __global__ __launch_bounds__(256) void head_psample_kernel(const float* __restri
         tail_fetch(X, z, RNG, b, l, N, C, xv, zv);
         __syncthreads();
         if (mine)
-            head_psample_item<FINISH, RNG, (CIN > 0 ? CIN : 4)>(hv, xv, zv, i, b, l, sw, sw + 8 * CIN, X, eps_out, xin, sg, N, C, c1, sqrt_alpha, beta, zero_row0, seed, rng_step, cond, elem0);
+            head_psample_item<FINISH, RNG, (CIN > 0 ? CIN : 4)>(hv, xv, zv, i, b, l, sw, sw + 8 * CIN, X, eps_out, xin, sg, N, C, c1, sqrt_alpha, beta, zero_row0, seed, rng_step, cond);
         return;
     }
     if (i >= B * N) return;
@@ -251,7 +221,7 @@ __global__ __launch_bounds__(256) void head_psample_kernel(const float* __restri
     const float* hp = h + (size_t)i * Cin;
     float xo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float zr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (RNG) rng_normal8(seed, (uint32_t)rng_step, (uint32_t)i + elem0, zr);
+    if (RNG) rng_normal8(seed, (uint32_t)rng_step, (uint32_t)i, zr);
     // each thread's Cin inputs are read ONCE (float4) and reused by all C outputs; weights are wave-uniform (scalar loads)
     float acc[8];
 #pragma unroll
@@ -341,24 +311,18 @@ static int set_startgoal(edmp_ctx* ctx, const double* start, const double* goal,
 // the start/goal conditioning and writes the next input.  Otherwise (teacher-forced API): X comes from the caller, is
 // packed here, and conditioning is left to step_b so that the un-conditioned posterior can be returned.
 static int step_a(edmp_ctx* ctx, double* X, const double* z, int B, int t, int zero_row0, int guided, float* eps_out, double* xpost_out,
-                  bool fused, bool use_rng = false, uint64_t seed = 0, const Span* span = nullptr, int gbuf = 0) {
+                  bool fused, bool use_rng = false, uint64_t seed = 0) {
     Sampler* s = ctx->sampler;
     UNet* u = ctx->unet;
     const int C = u->desc.input_dim, N = u->desc.horizon;
-    // the rows this call works on: the whole batch on the context's stream, or one chain's share on its stream.  Xs / zs / xin are
-    // the chain's first row; X stays the whole batch for the guide kernel, which indexes rows globally
-    const int r0 = span ? span->r0 : 0, nr = span ? span->n : B;
-    hipStream_t st = span ? span->st : ctx->stream;
-    double* Xs = X + (size_t)r0 * C * N;
-    const double* zs = z ? z + (size_t)r0 * C * N : nullptr;
-    float* xin = u->x_in + (size_t)r0 * N * 8;
-    const float* hlast = u->h_last + unet_chain_offset(u, u->h_last, r0);  // the chain's slice of the buffer (unet_run_program)
-    const unsigned elem0 = (unsigned)r0 * (unsigned)N;
-    const int n = nr * C * N;
-    const dim3 grid_bn((nr * N + 255) / 256);
-    if (!fused) hipLaunchKernelGGL(pack_state_kernel, grid_bn, dim3(256), 0, st, Xs, xin, nr, C, N);
+    hipStream_t st = ctx->stream;
+    float* xin = u->x_in;
+    const float* hlast = u->h_last;
+    const int n = B * C * N;
+    const dim3 grid_bn((B * N + 255) / 256);
+    if (!fused) hipLaunchKernelGGL(pack_state_kernel, grid_bn, dim3(256), 0, st, X, xin, B, C, N);
     const bool g = guided && guided_step(t);
-    const int zr = (zero_row0 && t == 1 && r0 == 0) ? 1 : 0;  // Q3: global row 0 only
+    const int zr = (zero_row0 && t == 1) ? 1 : 0;  // Q3: row 0 only
     const int rstep = 1 + (s->T - t);
     // device-resident loop: the step's tail (final 1x1 conv, posterior, conditioning, next input) rides in the UNet's last
     // launch when the architecture ends in the fused final level (tail.h); the teacher-forced API keeps the separate launch
@@ -366,8 +330,8 @@ static int step_a(edmp_ctx* ctx, double* X, const double* z, int B, int t, int z
     bool tail_done = false;
     const bool want_tail = fused && !eps_out && !xpost_out;
     if (want_tail) {
-        tail.X = Xs;
-        tail.z = zs;
+        tail.X = X;
+        tail.z = z;
         tail.xin = g ? nullptr : xin;
         tail.sg = s->sg;
         tail.C = C;
@@ -381,11 +345,10 @@ static int step_a(edmp_ctx* ctx, double* X, const double* z, int B, int t, int z
         tail.cond = s->condition;
         tail.finish = g ? 0 : 1;
         tail.rng = use_rng ? 1 : 0;
-        tail.elem0 = elem0;
     }
-    int rc = unet_run_program(ctx, nr, t, want_tail ? &tail : nullptr, &tail_done, r0, span ? st : nullptr);
+    int rc = unet_run_program(ctx, B, t, want_tail ? &tail : nullptr, &tail_done);
     if (rc) return rc;
-#define EDMP_HP_ARGS(xin_ptr) hlast, u->head_w, u->head_b, Xs, zs, eps_out, (xin_ptr), s->sg, nr, N, u->head_cin, C, s->c1[t - 1], s->sqrt_alpha[t - 1], s->beta[t - 1], zr, seed, rstep, s->condition, elem0
+#define EDMP_HP_ARGS(xin_ptr) hlast, u->head_w, u->head_b, X, z, eps_out, (xin_ptr), s->sg, B, N, u->head_cin, C, s->c1[t - 1], s->sqrt_alpha[t - 1], s->beta[t - 1], zr, seed, rstep, s->condition
 #define EDMP_HP_LAUNCH(FIN, RN, xin_ptr)                                                                                              \
     {                                                                                                                                  \
         if (u->head_cin == 32) hipLaunchKernelGGL((head_psample_kernel<FIN, RN, 32>), grid_bn, dim3(256), 0, st, EDMP_HP_ARGS(xin_ptr));      \
@@ -404,26 +367,25 @@ static int step_a(edmp_ctx* ctx, double* X, const double* z, int B, int t, int z
 #undef EDMP_HP_LAUNCH
 #undef EDMP_HP_ARGS
     EDMP_HIP_CHECK(hipGetLastError());
-    if (xpost_out) EDMP_HIP_CHECK(hipMemcpyAsync(xpost_out, Xs, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (xpost_out) EDMP_HIP_CHECK(hipMemcpyAsync(xpost_out, X, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (g) {
-        rc = guide_raw_gradient_from_X(ctx, X, B, N, t, /*reduce=*/!(fused && !s->ar_fn), r0, r0 + nr, gbuf, span ? st : nullptr);
+        rc = guide_raw_gradient_from_X(ctx, X, B, N, t, /*reduce=*/!(fused && !s->ar_fn));
         if (rc) return rc;
     }
     return EDMP_OK;
 }
 
-static int step_b(edmp_ctx* ctx, double* X, int B, int t, int guided, double* grad_out, bool fused, const Span* span = nullptr, int gbuf = 0) {
+static int step_b(edmp_ctx* ctx, double* X, int B, int t, int guided, double* grad_out, bool fused) {
     Sampler* s = ctx->sampler;
     UNet* u = ctx->unet;
     const int C = u->desc.input_dim, N = u->desc.horizon;
-    const int r0 = span ? span->r0 : 0, nr = span ? span->n : B;
-    hipStream_t st = span ? span->st : ctx->stream;
+    hipStream_t st = ctx->stream;
     if (guided && guided_step(t)) {
-        const int i0 = r0 * C * N, n = nr * C * N;
-        hipLaunchKernelGGL(update_kernel, dim3((n + 255) / 256), dim3(256), 0, st, X, guide_graw(ctx), guide_sumsq(ctx), (fused && !s->ar_fn) ? guide_rowsq(ctx, gbuf) : nullptr, guide_grad_norm(ctx),
-                           guide_sched(ctx), guide_rows_T(ctx), t, B, C, N, s->sg, 1, grad_out, fused ? u->x_in : nullptr, s->condition, i0, i0 + n);
+        const int n = B * C * N;
+        hipLaunchKernelGGL(update_kernel, dim3((n + 255) / 256), dim3(256), 0, st, X, guide_graw(ctx), guide_sumsq(ctx), (fused && !s->ar_fn) ? guide_rowsq(ctx) : nullptr, guide_grad_norm(ctx),
+                           guide_sched(ctx), guide_rows_T(ctx), t, B, C, N, s->sg, 1, grad_out, fused ? u->x_in : nullptr, s->condition, n);
     } else if (!fused && s->condition) {
-        hipLaunchKernelGGL(condition_kernel, dim3((nr * C + 255) / 256), dim3(256), 0, st, X + (size_t)r0 * C * N, nr, C, N, s->sg);
+        hipLaunchKernelGGL(condition_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, X, B, C, N, s->sg);
     }  // fused + unguided: head_psample_kernel<true> already conditioned X and wrote the next input
     EDMP_HIP_CHECK(hipGetLastError());
     return EDMP_OK;
@@ -639,116 +601,6 @@ extern "C" int edmp_step_b_dev(edmp_ctx* ctx, double* X_dev, int B, int t, const
 
 extern "C" double* edmp_sumsq_ptr_dev(edmp_ctx* ctx) { return ctx ? guide_sumsq(ctx) : nullptr; }
 
-// ---- row chains of one batch ---------------------------------------------------------------------------------------------
-// how many chains this call runs as: the configured count, 1 for runs that cannot be split (a cross-rank hook between the two
-// halves of a guided step, per-launch profiling brackets) or are too small to split on whole sample tiles.  A count > 1 switches
-// hipGraph replay off for the call (denoise_loop: `graph = ... && loop_chains(...) == 1`)
-static int loop_chains(edmp_ctx* ctx, int B, int guided) {
-    Sampler* s = ctx->sampler;
-    (void)guided;
-    int k = s->chains;
-    if (k <= 1 || s->ar_fn || ctx->prof.on) return 1;
-    if (k > B) k = B;
-    return k;
-}
-
-// chain c's rows: boundaries on multiples of 32 rows (the largest sample tile of the conv kernels; the level kernels take 2 / 4,
-// the guide kernel 4 rows per workgroup) whenever every chain can have at least one full tile, so that no chain adds a ragged tile
-static void chain_rows(int B, int K, int c, int* r0, int* r1) {
-    const int align = (B >= 32 * K) ? 32 : 1;
-    const int units = (B + align - 1) / align;
-    const int u0 = (int)((long long)units * c / K), u1 = (int)((long long)units * (c + 1) / K);
-    *r0 = std::min(B, u0 * align);
-    *r1 = std::min(B, u1 * align);
-}
-
-static int ensure_chain_resources(edmp_ctx* ctx, int K) {
-    Sampler* s = ctx->sampler;
-    while ((int)s->cstream.size() < K - 1) {
-        hipStream_t st;
-        EDMP_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        s->cstream.push_back(st);
-    }
-    for (int b = 0; b < 2; ++b)
-        while ((int)s->ev_grad[b].size() < K) {
-            hipEvent_t e;
-            EDMP_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            s->ev_grad[b].push_back(e);
-        }
-    while ((int)s->ev_done.size() < K) {
-        hipEvent_t e;
-        EDMP_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        s->ev_done.push_back(e);
-    }
-    if (!s->ev_fork) EDMP_HIP_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-    return EDMP_OK;
-}
-
-// steps t_hi .. t_lo+1 of the device-resident loop as K row chains.  Entered with the state (X, first UNet input) complete on the
-// context's stream; left with every chain joined back into it.
-static int enqueue_chains(edmp_ctx* ctx, int K, const double* noise_dev, bool use_rng, uint64_t seed, int B, int guided, int t_hi, int t_lo, int zero_row0) {
-    Sampler* s = ctx->sampler;
-    const int C = ctx->unet->desc.input_dim, N = ctx->unet->desc.horizon;
-    const size_t n = (size_t)B * C * N;
-    int rc = ensure_chain_resources(ctx, K);
-    if (rc) return rc;
-    if (guided) {  // scratch sized before the chains start: no chain may (re)allocate what another one is using
-        rc = guide_prepare(ctx, B, N - 2);
-        if (rc) return rc;
-    }
-    std::vector<Span> sp(K);
-    for (int c = 0; c < K; ++c) {
-        int r0, r1;
-        chain_rows(B, K, c, &r0, &r1);
-        sp[c].r0 = r0, sp[c].n = r1 - r0, sp[c].B = B;
-        sp[c].st = c == 0 ? ctx->stream : s->cstream[c - 1];
-        EDMP_REQUIRE(sp[c].n > 0, "chain %d of %d has no rows (batch %d)", c, K, B);
-    }
-    EDMP_HIP_CHECK(hipEventRecord(s->ev_fork, ctx->stream));
-    for (int c = 1; c < K; ++c) EDMP_HIP_CHECK(hipStreamWaitEvent(sp[c].st, s->ev_fork, 0));
-    // an error in the middle leaves work of the other chains enqueued on their streams: drain them before the error travels up, so
-    // that nothing still runs on buffers the caller may release (the message of the first error is kept)
-    auto fail = [&](int code) {
-        const std::string msg = g_err;
-        for (int c = 1; c < K; ++c) (void)hipStreamSynchronize(sp[c].st);
-        g_err = msg;
-        return code;
-    };
-#define EDMP_CHAIN_HIP(expr)                                                                           \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess) {                                                                        \
-            set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_));            \
-            return fail(EDMP_ERR_HIP);                                                                 \
-        }                                                                                              \
-    } while (0)
-    int gstep = 0;  // guided steps so far: selects the partial-sum buffer
-    for (int t = t_hi; t > t_lo; --t) {
-        const double* z = use_rng ? nullptr : noise_dev + (size_t)(t_hi - t) * n;
-        const bool g = guided && guided_step(t);
-        const int buf = gstep & 1;
-        for (int c = 0; c < K; ++c) {
-            rc = step_a(ctx, s->X, z, B, t, zero_row0, guided, nullptr, nullptr, true, use_rng, seed, &sp[c], buf);
-            if (rc) return fail(rc);
-            if (g) EDMP_CHAIN_HIP(hipEventRecord(s->ev_grad[buf][c], sp[c].st));
-        }
-        for (int c = 0; c < K; ++c) {
-            if (g)  // the whole batch's partial sums are in place before any chain normalises by their total
-                for (int o = 0; o < K; ++o)
-                    if (o != c) EDMP_CHAIN_HIP(hipStreamWaitEvent(sp[c].st, s->ev_grad[buf][o], 0));
-            rc = step_b(ctx, s->X, B, t, guided, nullptr, true, &sp[c], buf);
-            if (rc) return fail(rc);
-        }
-        if (g) ++gstep;
-    }
-    for (int c = 1; c < K; ++c) {
-        EDMP_CHAIN_HIP(hipEventRecord(s->ev_done[c], sp[c].st));
-        EDMP_CHAIN_HIP(hipStreamWaitEvent(ctx->stream, s->ev_done[c], 0));
-    }
-#undef EDMP_CHAIN_HIP
-    return EDMP_OK;
-}
-
 // The reverse loop for steps t_hi .. t_lo+1.  `init`: build X_T first (noise_dev[0] or the device RNG) and condition it;
 // otherwise continue from the state left in the context by the previous segment.  noise_dev points at the first draw
 // this segment consumes: [X_T draw if init][z of step t_hi][z of step t_hi-1]...  X_out_dev may be NULL (segment in the
@@ -773,13 +625,6 @@ static int enqueue_loop(edmp_ctx* ctx, const double* noise_dev, bool use_rng, ui
             hipLaunchKernelGGL(pack_state_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, s->X, ctx->unet->x_in, B, C, N);
             noise_dev += n;
         }
-    }
-    const int K = loop_chains(ctx, B, guided);
-    if (K > 1) {
-        int rc2 = enqueue_chains(ctx, K, noise_dev, use_rng, seed, B, guided, t_hi, t_lo, zero_row0);
-        if (rc2) return rc2;
-        if (X_out_dev) EDMP_HIP_CHECK(hipMemcpyAsync(X_out_dev, s->X, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-        return EDMP_OK;
     }
     for (int t = t_hi; t > t_lo; --t) {
         const double* z = use_rng ? nullptr : noise_dev + (size_t)(t_hi - t) * n;
@@ -831,7 +676,7 @@ static int denoise_loop(edmp_ctx* ctx, const double* noise_dev, bool use_rng, ui
     }
     // a caller-supplied collective is not capturable; segments of a chunked run carry a fresh noise pointer each, so a
     // captured graph would never be replayed (capture + instantiate + destroy per chunk): they are enqueued directly
-    const bool graph = allow_graph && s->graph_on == 1 && !ctx->prof.on && (!s->ar_fn || sampler_hook_is_native(s)) && loop_chains(ctx, B, guided) == 1;
+    const bool graph = allow_graph && s->graph_on == 1 && !ctx->prof.on && (!s->ar_fn || sampler_hook_is_native(s));
     Sampler::GraphKey key;
     if (graph) {
         if (guided) {
@@ -896,16 +741,6 @@ extern "C" int edmp_sampler_set_allreduce(edmp_ctx* ctx, edmp_allreduce_fn fn, v
     EDMP_REQUIRE(ctx && ctx->sampler, "sampler not initialised");
     ctx->sampler->ar_fn = fn;
     ctx->sampler->ar_user = user;
-    return EDMP_OK;
-}
-
-extern "C" int edmp_sampler_set_chains(edmp_ctx* ctx, int chains) {
-    EDMP_REQUIRE(ctx && ctx->sampler, "sampler not initialised");
-    EDMP_REQUIRE(chains >= 1 && chains <= 16, "chains must lie in 1..16, got %d", chains);
-    EDMP_HIP_CHECK(hipSetDevice(ctx->device));
-    EDMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    ctx->sampler->chains = chains;
-    ctx->epoch++;
     return EDMP_OK;
 }
 

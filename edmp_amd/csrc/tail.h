@@ -70,10 +70,6 @@ struct TailP {
     int cond = 0;
     int finish = 0;  // steps without guidance: condition X and write the next UNet input
     int rng = 0;     // device noise (Philox) instead of z
-    // row-sharded chains of one batch (sampler.hip): X / z / xin point at the chain's first row; elem0 = that row's (sample,
-    // waypoint) index in the whole batch, which the device noise source is keyed on.  zero_row0 is only set for the chain
-    // that holds global row 0.
-    unsigned elem0 = 0;
 };
 
 // eps[c] = final 1x1 conv of the UNet (final_conv.1, temporalunet.py:36) on the CIN activations hv of (sample b, waypoint l);
@@ -99,10 +95,10 @@ template <bool FINISH, bool RNG, int CIN>
 __device__ __forceinline__ void head_psample_item(const float4 (&hv)[CIN / 4], const double (&xv)[8], const double (&zv)[8], int i, int b, int l,
                                                   const float* __restrict__ w, const float* __restrict__ bias, double* __restrict__ X,
                                                   float* __restrict__ eps_out, float* __restrict__ xin, const double* __restrict__ sg, int N, int C, double c1,
-                                                  double sqrt_alpha, double beta, int zero_row0, uint64_t seed, int rng_step, int cond, unsigned elem0 = 0u) {
+                                                  double sqrt_alpha, double beta, int zero_row0, uint64_t seed, int rng_step, int cond) {
     float xo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float zr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (RNG) rng_normal8(seed, (uint32_t)rng_step, (uint32_t)i + elem0, zr);
+    if (RNG) rng_normal8(seed, (uint32_t)rng_step, (uint32_t)i, zr);
     float acc[8];
 #pragma unroll
     for (int co = 0; co < 8; ++co) acc[co] = (co < C) ? bias[co] : 0.0f;

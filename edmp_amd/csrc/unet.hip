@@ -789,11 +789,6 @@ static void op_kernel_name(const Op& op, char* out) {
     }
 }
 
-// float offset of the first row of a chain that starts at batch row r0, for a tensor living in buffer `p` (unet_run_program)
-size_t unet_chain_offset(const UNet* u, const float* p, int r0) {
-    if (p == u->x_in) return (size_t)r0 * u->desc.horizon * 8;  // dense [B][N][8], shared with the sampler kernels
-    return (size_t)r0 * (u->buf_cap / (size_t)u->max_batch);
-}
 
 bool unet_complete(const UNet* u) { return u && u->wpack && u->tbias && !u->prog.empty(); }
 
@@ -1638,21 +1633,12 @@ namespace edmp {
 // run the layer program on u->x_in ([B][N][8], already filled); leaves the head input in u->h_last
 // `tail` (device-resident loop): if the program ends with the fused final level (LV_UP_FINAL, 32 channels into the head) the
 // tail of the reverse step runs inside that launch and *tail_done is set; otherwise the caller launches head_psample_kernel
-// `r0`, `run_stream`: the rows [r0, r0 + B) of the batch on another stream (one chain of a row-sharded run, sampler.hip); the
-// caller has offset the tail's pointers likewise.  Row ranges are independent (a workgroup never mixes samples of different tiles
-// in one reduction), so the chains' results are bit-identical to the single launch over all rows.
-// Where a chain's rows live: activation buffers are recycled between layers of different (L, C), and concurrent chains are at
-// different layers - so a chain does NOT use rows r0.. of the dense [B][L][C] tensor (chain A's rows of a wide tensor would
-// overlap chain B's rows of a narrow one in the same buffer) but its own slice of every buffer: a dense [B_chain][L][C] tensor at
-// float offset r0 * (buffer capacity per batch row).  The UNet input x_in is the exception: never recycled, written by the
-// sampler kernels with whole-batch indices, so it keeps the dense layout (unet_chain_offset).
-int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_done, int r0, hipStream_t run_stream) {
+int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_done) {
     if (tail_done) *tail_done = false;
     UNet* u = ctx->unet;
     EDMP_REQUIRE(u, "edmp_unet_load has not been called");
-    EDMP_REQUIRE(B >= 1 && r0 >= 0 && r0 + B <= u->max_batch, "rows %d..%d outside 0..max_batch=%d", r0, r0 + B, u->max_batch);
-    hipStream_t main_stream = run_stream ? run_stream : ctx->stream;
-    EDMP_REQUIRE(r0 == 0 || !ctx->prof.on, "per-launch event brackets are recorded for whole-batch runs only");
+    EDMP_REQUIRE(B >= 1 && B <= u->max_batch, "batch %d outside 1..max_batch=%d", B, u->max_batch);
+    hipStream_t main_stream = ctx->stream;
     EDMP_REQUIRE(t >= 1 && t <= u->desc.T, "t=%d outside 1..T=%d", t, u->desc.T);
     const float* trow = u->tbias + (size_t)(t - 1) * u->tb_stride;
     Prof& pf = ctx->prof;
@@ -1668,7 +1654,6 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
         }
         EDMP_HIP_CHECK(hipEventRecord(whole.a, main_stream));
     }
-    auto coff = [&](auto* q) { return q ? q + unet_chain_offset(u, q, r0) : q; };
     // the tail of the reverse step runs inside the last level's launch when that level is the program's last op (LV_UP_FINAL, 32 channels)
     auto fuse_step_tail = [&](LevelP& p, const Op& o, int index, bool out_is_head_input) {
         if (tail && tail_done && o.lv_variant == 4 && index + 1 == (int)u->prog.size() && u->head_cin == 32 && tail->N == u->desc.horizon && tail->C <= 8 && out_is_head_input) {
@@ -1701,7 +1686,6 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
         if (op.kind == OP_RCB) {
             RcbP p = op.rc;
             p.B = B;
-            p.src1 = coff(p.src1), p.src2 = coff(p.src2), p.dst = coff(p.dst), p.add_res = coff(p.add_res), p.res_out = coff(p.res_out);
             p.add_tb = op.tb_off >= 0 ? trow + op.tb_off : nullptr;
             EDMP_REQUIRE(!(p.add_tb && p.add_res), "fused conv block: a launch adds the time bias (conv1) or the residual (conv2), not both");
             rc = launch_rcb(p, op.rc_L, op.rc_form, op.rc_ms, op.rc_bf3, s);
@@ -1710,8 +1694,7 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
             LevelP pa = op.lv, pb = nx.lv;
             pa.B = pb.B = B;
             const bool out_is_head_input = pb.out == u->h_last;
-            pa.src1 = coff(pa.src1), pa.src2 = coff(pa.src2), pa.skip_out = coff(pa.skip_out), pa.out = nullptr;
-            pb.src1 = nullptr, pb.src2 = coff(pb.src2), pb.skip_out = coff(pb.skip_out), pb.out = coff(pb.out);  // (level B's first input half arrives in LDS)
+            pa.out = nullptr, pb.src1 = nullptr;  // (level B's first input half arrives in LDS)
             pa.tb1 = trow + op.lv_tb1, pa.tb2 = trow + op.lv_tb2;
             pb.tb1 = trow + nx.lv_tb1, pb.tb2 = trow + nx.lv_tb2;
             fuse_step_tail(pb, nx, op_index + 1, out_is_head_input);
@@ -1721,7 +1704,6 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
             LevelP p = op.lv;
             p.B = B;
             const bool out_is_head_input = p.out == u->h_last;
-            p.src1 = coff(p.src1), p.src2 = coff(p.src2), p.skip_out = coff(p.skip_out), p.out = coff(p.out);
             p.tb1 = trow + op.lv_tb1;
             p.tb2 = trow + op.lv_tb2;
             fuse_step_tail(p, op, op_index, out_is_head_input);
@@ -1729,17 +1711,14 @@ int unet_run_program(edmp_ctx* ctx, int B, int t, const TailP* tail, bool* tail_
         } else if (op.kind == OP_WRS) {
             RcbP p = op.rc;
             p.B = B;
-            p.src1 = coff(p.src1), p.dst = coff(p.dst);
             rc = launch_wrs(p, op.wrs_kind, op.rc_L, op.rc_ms, op.rc_bf3, s);
         } else if (op.kind == OP_CONV) {
             ConvP p = op.cv;
             p.B = B;
-            p.src1 = coff(p.src1), p.src2 = coff(p.src2), p.dst = coff(p.dst);
             launch_conv(p, s);
         } else {
             GnP g = op.gn;
             g.B = B;
-            g.y = coff(g.y), g.add_res = coff(g.add_res);
             g.add_tbias = op.tb_off >= 0 ? trow + op.tb_off : nullptr;
             rc = launch_gn(g, s);
         }
@@ -1800,7 +1779,7 @@ int unet_forward_impl(edmp_ctx* ctx, const float* x_dev, int B, int t, float* ep
         int total = B * N * 8;
         hipLaunchKernelGGL(pack_input_kernel, dim3((total + 255) / 256), dim3(256), 0, s, x_dev, u->x_in, B, C, N, 8);
     }
-    int rc = unet_run_program(ctx, B, t, nullptr, nullptr, 0, nullptr);
+    int rc = unet_run_program(ctx, B, t, nullptr, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(head_1x1_kernel, dim3((B * N + 255) / 256), dim3(256), 0, s, u->h_last, u->head_w, u->head_b, eps_dev, B, N,
                        u->head_cin, C);

@@ -70,8 +70,6 @@ class Diffusion:
         self.ctx = get_context(device)
         self.device = self.ctx.device
         self.ctx.ensure_sampler(self.T, self.variance_thresh)
-        # row chains of one batch in the device-resident loop (denoise_guided(chains=...)): 1 unless the caller sets it
-        self.chains = 1
         self.beta = np.zeros(self.T)
         self.alpha = np.zeros(self.T)
         self.alpha_bar = np.zeros(self.T)
@@ -159,21 +157,15 @@ class Diffusion:
             guide._set_rows(guidance_schedule if guidance_schedule is not None else guide._sched)
 
     def denoise_guided(self, model, guide, traj_len, num_channels, guidance_schedule, batch_size=1, start=None, goal=None,
-                       condition=True, benchmarking=False, *, noise=None, seed=0, t_stop=0, zero_row0=True, return_device=False, chunk_steps=16, allreduce=None,
-                       chains=None):
+                       condition=True, benchmarking=False, *, noise=None, seed=0, t_stop=0, zero_row0=True, return_device=False, chunk_steps=16, allreduce=None):
         """diffusion.py:300-356.  ``noise``: optional pre-drawn (T+1,B,C,N) f64 ndarray / device tensor (default:
         drawn from the global NumPy RNG in the reference's order); ``noise="device"`` draws z on the GPU (Philox,
         ``seed``) — a non-parity mode without the host draw / upload.  ``allreduce``: this call is one row shard
         of a batch spread over several GPUs; an ``edmp_amd.dist.RcclAllReduce`` (native ncclAllReduce inside the device loop) or a
-        callable that sums the f64 device scalar over ranks in place (edmp_amd.dist.allreduce_sum_; a Python callback per guided step).  ``chains`` (default: the diffuser's ``self.chains``, 1): run the batch as that many
-        row-sharded chains on separate HIP streams (edmp_sampler_set_chains) - bit-identical results, see include/edmp_hip.h.
+        callable that sums the f64 device scalar over ranks in place (edmp_amd.dist.allreduce_sum_; a Python callback per guided step).
         Returns (B,C,N) f64 ndarray (a fresh copy)."""
         ctx = self.ctx
         self._prepare(model, guide, batch_size, guidance_schedule)
-        k = int(self.chains if chains is None else chains)
-        if k != getattr(ctx, "_chains", 1):
-            _capi.check(ctx.lib.edmp_sampler_set_chains(ctx.h, k), "edmp_sampler_set_chains")
-            ctx._chains = k
         _capi.check(ctx.lib.edmp_sampler_set_condition(ctx.h, 1 if condition else 0))
         s, g = _startgoal(start, goal, needed=bool(condition) or guide is not None)
         if int(traj_len) != model.horizon or int(num_channels) != model.input_dim:
@@ -206,7 +198,7 @@ class Diffusion:
                 _read_stats()
                 try:
                     return self.denoise_guided(model, guide, traj_len, num_channels, guidance_schedule, batch_size, start, goal, condition, benchmarking,
-                                               noise=noise, seed=seed, t_stop=t_stop, zero_row0=zero_row0, return_device=return_device, chains=chains)
+                                               noise=noise, seed=seed, t_stop=t_stop, zero_row0=zero_row0, return_device=return_device)
                 finally:
                     _capi.check(ctx.lib.edmp_rccl_enable(ctx.h, 0), "edmp_rccl_enable")  # other runs of this context are not shards
                     _read_stats()
@@ -227,7 +219,7 @@ class Diffusion:
             _read_stats()
             try:
                 res = self.denoise_guided(model, guide, traj_len, num_channels, guidance_schedule, batch_size, start, goal, condition, benchmarking,
-                                          noise=noise, seed=seed, t_stop=t_stop, zero_row0=zero_row0, return_device=return_device, chains=chains)
+                                          noise=noise, seed=seed, t_stop=t_stop, zero_row0=zero_row0, return_device=return_device)
             except _capi.EdmpError:
                 if self._hook_error is not None:
                     raise self._hook_error

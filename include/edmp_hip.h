@@ -195,16 +195,6 @@ int edmp_rng_normal_dev(edmp_ctx* ctx, uint64_t seed, int step_index, int B, int
  * measured neutral on MI355X at B = 4..1024 - the loop is bound by kernel execution, not by launch. */
 int edmp_sampler_set_graph(edmp_ctx* ctx, int on);
 
-/* Row chains of ONE batch (no reference counterpart; the reference's loop is a single stream of PyTorch ops,
- * diffusion/diffusion.py:309-349): the device-resident loop of edmp_denoise_guided*_dev runs the B rows as `chains` contiguous
- * row ranges (boundaries on multiples of 32 rows), each on its own HIP stream - a chain's dispatch gaps and kernel tails can be
- * filled by another chain's launches.  Rows are independent except for the whole-batch sum(g^2) of a guided step
- * (lib/guide.py:629): every chain writes its rows' partial sums, waits (HIP events) until all chains have, and normalises by the
- * total formed in the single-chain summation order, so results are BIT-IDENTICAL to chains = 1 (Q7's NaN rule included).
- * Ignored (= 1) while an all-reduce hook or profiling brackets are active.  chains > 1 takes precedence over hipGraph replay
- * (edmp_sampler_set_graph): such a call is enqueued eagerly, nothing is captured.  1 <= chains <= 16; default 1. */
-int edmp_sampler_set_chains(edmp_ctx* ctx, int chains);
-
 /* ---- training-side forward process --------------------------------------------------------- */
 /* replaces the arithmetic of Diffusion.q_sample (diffusion/diffusion.py:52-77, cumulative = 0: a = alpha),
  * Diffusion.q_sample_from_x0 (:79-105, cumulative = 1: a = alpha_bar) and the conditioning of generate_q_sample

@@ -14,7 +14,7 @@ b = json.load(open(os.path.join(P, f"{R}_bench.json")))
 rf = b["roofline"]
 print(f"# {R} - numbers derived from the committed profile files (scripts/round_numbers.py {R})\n")
 print("## bench.py line (`%s_bench.json`)\n" % R)
-print(f"* value **{b['value']:.0f} {b['unit']}**, ms_per_step {b['ms_per_step']:.2f}, n_gpus {b['n_gpus']}, row_chains {b['config'].get('row_chains')}")
+print(f"* value **{b['value']:.0f} {b['unit']}**, ms_per_step {b['ms_per_step']:.2f}, n_gpus {b['n_gpus']}")
 print(f"* roofline: issued {rf['achieved']:.1f} TFLOP/s = **{rf['frac']:.3f}** of {rf['peak']}; direct form {rf['achieved_direct_form']:.1f} = {rf['frac_direct_form']:.3f}; nominal {rf['achieved_nominal']:.1f}; "
       f"conv {rf['conv_ms_per_call']:.1f} ms per call over {rf['launches']} launches (avg {rf['avg_launch_us']:.2f} us), share of the step {rf['conv_share_of_step']:.3f}")
 if rf.get("hbm"):

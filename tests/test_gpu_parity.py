@@ -1918,77 +1918,6 @@ def test_context_close_releases_the_gpu_and_lanes_are_cached():
         net(torch.randn(4, 7, 50, device=DEV), torch.tensor([7.0]))
 
 
-@pytest.mark.parametrize("guides", [[1, 2, 3, 4, 5, 10], [1, 2, 3, 4, 5, 10, 11, 13]])
-def test_row_chains_are_bit_identical_at_full_size(guides):
-    """ONE batch of 1024 rows as 2 / 3 / 4 row-sharded chains on separate HIP streams
-    (Diffusion.denoise_guided(chains=k), edmp_sampler_set_chains).  Rows only meet in the whole-batch sum(g^2) (lib/guide.py:629):
-    every chain writes its rows' partial sums, all chains wait for all of them, every update kernel sums ALL rows in the
-    single-chain order.  The result must equal chains = 1 BIT FOR BIT - BASELINE config 3's ensemble and config 5's (grad_norm rows
-    11, 13: the normalised gradient is where a differently ordered sum would show), the full network, 40 reverse steps (18 guided)."""
-    from edmp_amd import guide_cfg as GC
-    from edmp_amd import scenes
-    from edmp_amd.diffusion import Diffusion
-    from edmp_amd.guide import IntersectionVolumeGuide
-    from edmp_amd.temporalunet import TemporalUNet
-
-    B = 1024
-    cfgs = GC.build_guide_cfgs([GC.catalog_guide_dict(g) for g in guides], 0, T, rows_per_guide=GC.split_rows(B, len(guides)))
-    net = TemporalUNet(None, 7, 32, DEV, dims=FULL_DIMS, seed=1, max_batch=B)
-    guide = IntersectionVolumeGuide(scenes.random_scene(11, 16), DEV, cfgs, B)
-    dif = Diffusion(T, DEV)
-    rs = np.random.RandomState(99)
-    noise = dif.ctx.to_dev(rs.standard_normal((T + 1, B, 7, 50)), torch.float64)
-    kw = dict(batch_size=B, start=scenes.DEFAULT_START, goal=scenes.DEFAULT_GOAL, noise=noise, t_stop=T - 40)
-    ref = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], chains=1, **kw)
-    assert np.isfinite(ref).all()
-    for k in (2, 3, 4):
-        X = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], chains=k, **kw)
-        assert np.array_equal(X, ref), (k, float(np.abs(X - ref).max()))
-    # the device noise source is keyed on the global element index, the t = 1 zeroing on global row 0: chains change neither
-    kw2 = dict(batch_size=B, start=scenes.DEFAULT_START, goal=scenes.DEFAULT_GOAL, noise="device", seed=5)
-    a = dif.denoise_guided(net, None, 50, 7, None, chains=1, **kw2)
-    b = dif.denoise_guided(net, None, 50, 7, None, chains=3, **kw2)
-    assert np.array_equal(a, b)
-    # the NumPy-stream contract (segments of a chunked run) under chains
-    np.random.seed(3)
-    c1 = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=scenes.DEFAULT_START, goal=scenes.DEFAULT_GOAL, t_stop=T - 20, chains=1)
-    np.random.seed(3)
-    c2 = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], batch_size=B, start=scenes.DEFAULT_START, goal=scenes.DEFAULT_GOAL, t_stop=T - 20, chains=2)
-    assert np.array_equal(c1, c2)
-
-
-def test_row_chains_small_and_ragged_batches(tiny_net):
-    """chains on batches that do not split on 32-row tiles (generic fallback kernels of the tiny network, 1..12 rows, more chains than
-    rows, NaN poisoning of Q7 through the cross-chain sum): bit-identical to one chain."""
-    from edmp_amd import scenes
-    from edmp_amd.diffusion import Diffusion
-    from edmp_amd.guide import IntersectionVolumeGuide
-
-    net, _ = tiny_net
-    dif = Diffusion(T, DEV)
-    for guides, bpg, scene in (([1, 11], 3, scenes.random_scene(7, 8)), ([1, 10, 11, 13], 3, scenes.random_scene(8, 5)), ([11], 1, scenes.random_scene(7, 8))):
-        cfgs = cfgs_for(guides, bpg)
-        B = cfgs["total_batch_size"]
-        guide = IntersectionVolumeGuide(scene, DEV, cfgs, B)
-        kw = dict(batch_size=B, start=scenes.DEFAULT_START, goal=scenes.DEFAULT_GOAL, noise=noise_for(3, B), t_stop=T - 14)
-        ref = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], chains=1, **kw)
-        for k in (2, 5, 16):
-            X = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], chains=k, **kw)
-            assert np.array_equal(X, ref, equal_nan=True), (guides, k)
-    # Q7: the whole scene 10 m away -> zero batch gradient -> 0 * NaN poisons every row, in every chain
-    far = scenes.random_scene(7, 8)
-    far[:, 0] += 10.0
-    cfgs = cfgs_for([1, 11], 3)
-    B = cfgs["total_batch_size"]
-    guide = IntersectionVolumeGuide(far, DEV, cfgs, B)
-    kw = dict(batch_size=B, start=scenes.DEFAULT_START, goal=scenes.DEFAULT_GOAL, noise=noise_for(3, B), t_stop=T - 4)
-    ref = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], chains=1, **kw)
-    X = dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], chains=3, **kw)
-    assert np.isnan(ref[:, :, 1:-1]).all() and np.array_equal(X, ref, equal_nan=True)
-    with pytest.raises(Exception):
-        dif.denoise_guided(net, guide, 50, 7, cfgs["guidance_schedule"], chains=17, **kw)
-
-
 def _independent_issued_flops(dims, horizon, cin0_stored, bf3_mask, karatsuba=True):
     """Issued matrix FLOPs per trajectory of every launch of the layer program, counted HERE from the architecture alone
     (/root/reference/diffusion/models/temporalunet.py:47-76, blocks.py:13-34,137-166,213,251) and the documented kernel forms - nothing is read
