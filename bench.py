@@ -205,9 +205,9 @@ def main():
     value = world * B * T * args.steps / dt
 
     # ---- A/B leg (round 6): the same workload with EVERY conv on the fp32-MFMA kernels (EDMP_BF16X3=0 at model-build time) --------
-    # `value` is the default product path: 13 of the 40 conv launches of a reverse step form each fp32 product as six exact bf16
+    # `value` is the default product path: 20 of the 40 conv launches of a reverse step form each fp32 product as six exact bf16
     # partial products on the bf16 matrix pipe, fp32 accumulation (csrc/bf3.hip) - measured at HALF the fp32-MFMA kernels' error
-    # against float64 (profiles/r06_bf16x3.md, tests: test_bf16x3_split_layers_...).  The native leg keeps the two numbers side by side.
+    # against float64 (profiles/r06_bf16x3.md, tests: test_bf16x3_split_layers_are_at_least_as_accurate_as_the_fp32_mfma_layers).  The native leg keeps the two numbers side by side.
     native = None
     if not args.no_native_leg:
         env_prev = os.environ.get("EDMP_BF16X3")
@@ -257,9 +257,10 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "dtype_variant": (None if f32_bf16[1] == 0 else "f32 results, fp32 accumulation; the Conv1dBlocks at L=13 / L=7 (13 of 40 conv launches per reverse step) form every fp32 product as six "
-                              "EXACT bf16 x bf16 partial products on the bf16 matrix pipe (bf16x3 split, csrc/bf3.hip); error vs float64 0.36-0.75 x the fp32-MFMA kernels' "
-                              "(profiles/r06_bf16x3.md); EDMP_BF16X3=0 selects the all-fp32-MFMA program = value_native_f32"),
+            "dtype_variant": (None if f32_bf16[1] == 0 else "f32 results, fp32 accumulation; 20 of the 40 conv launches of a reverse step (Conv1dBlocks at L = 13 / 7 / 4 and the six k3s2 / ConvTranspose "
+                              "resamplers of the >= 128-channel levels) form every fp32 product as six EXACT bf16 x bf16 partial products on the bf16 matrix pipe (bf16x3 split, "
+                              "csrc/bf3.hip); error vs float64 0.43-0.62 x (rmse) and <= 1.03 x (max) the fp32-MFMA kernels' (profiles/r06_bf16x3.md); EDMP_BF16X3=0 selects the "
+                              "all-fp32-MFMA program = value_native_f32"),
             "value_bf16x3": (value if f32_bf16[1] > 0 else None),
             "value_native_f32": (value if f32_bf16[1] == 0 else (native["value"] if native else None)),
             "native_f32_leg": native,
@@ -474,7 +475,7 @@ def main():
         avg_s = 1e-3 * conv_ms / max(launches, 1)
         out["roofline"] = {
             "kernel": "MFMA conv family of the TemporalUNet: edmp::wide_conv_kernel (position-tile Conv1d k5 + GroupNorm + Mish, k3s2, ConvTranspose k4s2; fp32 MFMA, Karatsuba forms at L=2/4) + "
-                      "edmp::bf3_conv_kernel (the same op at L=13 / L=7 as six exact bf16 partial products per fp32 product on the bf16 pipe, fp32 accumulation) + "
+                      "edmp::bf3_conv_kernel (the same op at L=13 / 7 / 4 and the resamplers as six exact bf16 partial products per fp32 product on the bf16 pipe, fp32 accumulation) + "
                       "edmp::level_kernel (whole 32/64-channel levels, fp32 MFMA)",
             "bound": "mfma",
             "achieved": ach,
