@@ -379,3 +379,34 @@ def test_infer_serial_job_summary_and_rank_detection(monkeypatch):
     res = [dict(success_proxy=1, success_strict=0, rows_collision_free=3, rows=4, planning_time_s=0.5), dict(success_proxy=0, success_strict=0, rows_collision_free=0, rows=4, planning_time_s=0.25)]
     s = infer_serial.job_summary(res)
     assert s == dict(scenes=2, success_proxy=1, success_strict=0, rows_collision_free=3, rows=8, planning_time_s=0.75, ranks=1)
+
+
+def test_pinned_noise_stream_watermark():
+    """edmp_amd.diffusion.PinnedNoiseStream: the consumer blocks until the producer has published enough of the stream, and a producer error
+    reaches the consumer instead of a hang (infer_serial's feeder thread -> Diffusion.denoise_guided's chunked upload)."""
+    import threading
+    import time
+
+    import torch
+
+    from edmp_amd.diffusion import PinnedNoiseStream
+
+    st = PinnedNoiseStream(torch.zeros(8, dtype=torch.float64))
+    seen = []
+
+    def consumer():
+        for n in (2, 5, 8):
+            st.wait_until(n)
+            seen.append((n, st.drawn))
+
+    th = threading.Thread(target=consumer)
+    th.start()
+    for n in (1, 2, 6, 8):
+        time.sleep(0.02)
+        st.publish(n)
+    th.join(timeout=5)
+    assert not th.is_alive() and [s[0] for s in seen] == [2, 5, 8] and all(d >= n for n, d in seen)
+    bad = PinnedNoiseStream(torch.zeros(4, dtype=torch.float64))
+    bad.publish(1, error=RuntimeError("draw failed"))
+    with pytest.raises(RuntimeError, match="draw failed"):
+        bad.wait_until(3)
