@@ -15,6 +15,8 @@
 // hook installed (it is not with an arbitrary caller hook).
 #include <dlfcn.h>
 
+#include <mutex>
+
 namespace edmp {
 
 struct NcclId {
@@ -32,6 +34,7 @@ struct RcclApi {
     bool ok() const { return AllReduce != nullptr; }
 };
 static RcclApi g_rccl;
+static std::mutex g_rccl_mutex;  // edmp_rccl_load may be reached from several host threads (one context per scene in flight)
 
 struct RcclHook {
     void* comm = nullptr;
@@ -81,7 +84,8 @@ static int rccl_install(edmp_ctx* ctx, RcclHook* h) {
 
 extern "C" int edmp_rccl_load(const char* path) {
     using namespace edmp;
-    if (g_rccl.ok() && !path) return EDMP_OK;
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.ok() && !(path && path[0])) return EDMP_OK;
     void* so = nullptr;
     if (path && path[0]) {
         so = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
