@@ -205,7 +205,7 @@ def main():
     value = world * B * T * args.steps / dt
 
     # ---- A/B leg (round 6): the same workload with EVERY conv on the fp32-MFMA kernels (EDMP_BF16X3=0 at model-build time) --------
-    # `value` is the default product path: 20 of the 40 conv launches of a reverse step form each fp32 product as six exact bf16
+    # `value` is the default product path: 26 of the 40 conv launches of a reverse step form each fp32 product as six exact bf16
     # partial products on the bf16 matrix pipe, fp32 accumulation (csrc/bf3.hip) - measured at HALF the fp32-MFMA kernels' error
     # against float64 (profiles/r06_bf16x3.md, tests: test_bf16x3_split_layers_are_at_least_as_accurate_as_the_fp32_mfma_layers).  The native leg keeps the two numbers side by side.
     native = None
@@ -257,7 +257,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "dtype_variant": (None if f32_bf16[1] == 0 else "f32 results, fp32 accumulation; 20 of the 40 conv launches of a reverse step (Conv1dBlocks at L = 13 / 7 / 4 and the six k3s2 / ConvTranspose "
+            "dtype_variant": (None if f32_bf16[1] == 0 else "f32 results, fp32 accumulation; 26 of the 40 conv launches of a reverse step (the 20 Conv1dBlocks at L = 13 / 7 / 4 and the six k3s2 / ConvTranspose "
                               "resamplers of the >= 128-channel levels) form every fp32 product as six EXACT bf16 x bf16 partial products on the bf16 matrix pipe (bf16x3 split, "
                               "csrc/bf3.hip); error vs float64 0.43-0.62 x (rmse) and <= 1.03 x (max) the fp32-MFMA kernels' (profiles/r06_bf16x3.md); EDMP_BF16X3=0 selects the "
                               "all-fp32-MFMA program = value_native_f32"),
