@@ -212,11 +212,7 @@ __global__ __launch_bounds__(512) void bf3_conv_kernel(const float* a_src1, cons
     for (int k = 0; k < NA; ++k) {
         const int e = min(ptid + k * 256, A_F4 - 1);
         const int lp = e / (MS * 8), rem = e % (MS * 8);
-#ifdef EDMP_BF3_ROWPERM  // experiment: the four rows of a 32-lane group 4 apart (their 64-byte writes at the 80-byte row stride then tile the 64 banks)
-        const int j = rem >> 3, row = ((j & 3) << 2) + ((j >> 2) & 3) + ((j >> 4) << 4), quad = rem & 7;
-#else
         const int row = rem >> 3, quad = rem & 7;
-#endif
         const int sb = min(b0 + row, a_B - 1);
         a_g[k] = 4u * (unsigned)(((sb - b0) * LIN + lp) * a_C1 + 4 * quad);  // (a concatenated input has two halves of EQUAL width, launcher-checked)
         a_l[k] = lp * 3 * PLANE + row * RS + 4 * quad;
